@@ -1,0 +1,36 @@
+# quack-mi355x — top-level build (gfx950 only).
+#   make            libquack_hip.so (HIP kernels + C-ABI), host library + CLI
+#   make oracle     test oracle (plain C restatement, CPU)
+#   make tools      synthetic FASTQ generator, kbench
+HIPCC ?= /opt/rocm/bin/hipcc
+CC ?= gcc
+ARCH ?= gfx950
+HIPFLAGS ?= -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Iinclude -Wall -Wno-unused-function
+CFLAGS ?= -O2 -g -fPIC -std=c11 -Wall -Wextra -Iinclude -D_GNU_SOURCE
+
+CSRC := quack_amd/csrc
+HOST := quack_amd/host
+LIB_HIP := quack_amd/libquack_hip.so
+KERNEL_HDRS := $(CSRC)/qk_kernels.hip.h $(CSRC)/qk_adapter_kernels.hip.h
+
+.PHONY: all hip host oracle tools clean
+all: hip host
+
+hip: $(LIB_HIP)
+$(LIB_HIP): $(CSRC)/qk_shim.hip $(KERNEL_HDRS) include/quack_hip.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/qk_shim.hip -ldl
+
+host:
+	$(MAKE) -C $(HOST)
+
+oracle:
+	$(MAKE) -C oracle
+
+tools: tools/kbench
+tools/kbench: tools/kbench.cpp $(CSRC)/qk_shim.hip $(KERNEL_HDRS) include/quack_hip.h
+	$(HIPCC) $(HIPFLAGS) -DQK_ABLATION -o $@ tools/kbench.cpp $(CSRC)/qk_shim.hip -ldl
+
+clean:
+	rm -f $(LIB_HIP) tools/kbench
+	-$(MAKE) -C $(HOST) clean
+	-$(MAKE) -C oracle clean

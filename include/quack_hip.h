@@ -1,0 +1,152 @@
+/*
+ * quack_hip.h — C-ABI of the MI355X accumulation path ("libquack_hip.so").
+ *
+ * This is the drop-in boundary for quack's per-read statistics loop.  The
+ * reference has no plugin API; the seam is two C functions and two structs:
+ *
+ *     int*           read_adapters(char *adapters_file)          quack.c:154-178
+ *     sequence_data* read_fastq(char *fastq_file, int *kmers)    quack.c:180-228
+ *     base_information / sequence_data                           quack.c:134-146
+ *
+ * Everything below is `extern "C"`, plain pointers and sizes, no C++ or torch
+ * types.  A host (the C CLI in quack_amd/host, the Python mirror in
+ * quack_amd/, or quack.c itself via the stub shown in INTEGRATION.md) tokenises
+ * FASTQ on CPU cores and hands *read batches* to an accumulator; the
+ * accumulator owns device memory, pinned staging buffers and HIP streams, and
+ * returns exactly the table read_fastq() would have produced.
+ *
+ * Batch layout (host and device, identical):
+ *     seq [total]   sequence bytes of all reads, concatenated, no separators
+ *     qual[total]   quality bytes, same offsets
+ *     offsets[n+1]  u64 start offset of each read (offsets[n] == total);
+ *                   NULL for a fixed-length batch (read r starts at r*read_len)
+ * Algorithmic HBM traffic: 2 bytes per base (+ 8 bytes per read when ragged).
+ *
+ * Result layout: `qk_base_info`, bit-for-bit the reference's base_information
+ * (97 x u64 = 776 bytes per position, quack.c:134-139).
+ *
+ * Error convention: every function returns 0 on success and a negative
+ * QK_E* code on failure; qk_last_error() gives the message (thread-local).
+ * There is NO CPU fallback: without a usable HIP device every accumulator
+ * call fails with QK_ENODEV.
+ */
+#ifndef QUACK_HIP_H
+#define QUACK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QK_N_SCORES 91            /* quack.c:135  scores[91]            */
+#define QK_N_BASES 4              /* quack.c:136  content[4]: A,T,C,G   */
+#define QK_ROW_LENGTH 95          /* quack.c:137  length_count          */
+#define QK_ROW_KMER 96            /* quack.c:138  kmer_count            */
+#define QK_N_ROWS 97              /* u64 words per position             */
+#define QK_KMER_SIZE 10           /* quack.c:155,184                    */
+#define QK_KMER_TABLE_BITS (1u << 20)              /* 4^10 (quack.c:156) */
+#define QK_KMER_TABLE_WORDS (QK_KMER_TABLE_BITS / 32) /* 128 KiB bitset  */
+#define QK_TAIL_SLACK 16          /* readable bytes required after seq/qual */
+
+#define QK_OK 0
+#define QK_EINVAL (-1)            /* bad argument                        */
+#define QK_ENODEV (-2)            /* no HIP device / extension unusable  */
+#define QK_EHIP (-3)              /* a HIP runtime call failed           */
+#define QK_ENOMEM (-4)
+#define QK_ERCCL (-5)             /* an RCCL call failed                 */
+#define QK_ESTATE (-6)            /* call sequence violated              */
+
+/* Same memory image as the reference's base_information (quack.c:134-139). */
+typedef struct {
+  uint64_t scores[QK_N_SCORES];
+  uint64_t content[QK_N_BASES];
+  uint64_t length_count;
+  uint64_t kmer_count;
+} qk_base_info;
+
+/* Opaque accumulator: the state read_fastq() keeps in `bases`, `max_length`
+ * and `number_of_sequences` (quack.c:186-191), resident on one GPU. */
+typedef struct qk_accum qk_accum;
+
+/* ---- library ---------------------------------------------------------- */
+const char *qk_last_error(void);
+const char *qk_version(void);
+int qk_device_count(int *count);
+
+/* ---- accumulator life cycle  (replaces read_fastq, quack.c:180-228) ---- */
+
+/* kmer_bitset: QK_KMER_TABLE_WORDS words, bit i set <=> kmers[i] != 0 in the
+ * reference's table (quack.c:162-171), or NULL when no -a was given
+ * (kmers == NULL, quack.c:210).  max_len_hint sizes the first table
+ * allocation; the table grows when a longer read arrives (quack.c:194-198). */
+int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
+                    uint64_t max_len_hint);
+void qk_accum_destroy(qk_accum *acc);
+
+/* Zero-copy feed: borrow a pinned host batch buffer (double-buffered; blocks
+ * until one is free), fill it, commit it.  Capacities are in bytes / reads. */
+int qk_accum_acquire(qk_accum *acc, uint8_t **seq, uint8_t **qual,
+                     uint64_t **offsets, uint64_t *cap_bytes,
+                     uint64_t *cap_reads);
+/* offsets_used == 0: fixed-length batch of n_reads x read_len. */
+int qk_accum_commit(qk_accum *acc, uint64_t n_reads, uint64_t total_bytes,
+                    int offsets_used, uint32_t read_len);
+
+/* Copying feed from caller-owned host memory (any size; split internally). */
+int qk_accum_submit(qk_accum *acc, const uint8_t *seq, const uint8_t *qual,
+                    const uint64_t *offsets, uint64_t n_reads);
+int qk_accum_submit_fixed(qk_accum *acc, const uint8_t *seq,
+                          const uint8_t *qual, uint32_t read_len,
+                          uint64_t n_reads);
+
+/* Device-resident feed: pointers are device addresses (hipMalloc / a torch
+ * CUDA tensor's data_ptr) with QK_TAIL_SLACK readable bytes after `total`.
+ * d_offsets == NULL: fixed-length.  max_len: longest read in the batch.
+ * hip_stream: a hipStream_t (NULL = the accumulator's own stream). The call
+ * only enqueues; it does not synchronise. */
+int qk_accum_submit_device(qk_accum *acc, const void *d_seq,
+                           const void *d_qual, const void *d_offsets,
+                           uint64_t n_reads, uint64_t total_bytes,
+                           uint32_t max_len, void *hip_stream);
+
+/* Wait for everything enqueued so far. */
+int qk_accum_sync(qk_accum *acc);
+
+/* Current sizes: max_length and number_of_sequences (quack.c:225-226). */
+int qk_accum_stats(qk_accum *acc, uint64_t *max_len, uint64_t *n_reads);
+
+/* Device-side table for collectives: planar u64 [QK_N_ROWS][table_len] + 1
+ * trailing word (number_of_sequences).  Integer sums commute, so an
+ * all-reduce(SUM) over these words from N accumulators that saw disjoint read
+ * batches equals one accumulator that saw them all. */
+int qk_accum_table_words(qk_accum *acc, uint64_t *n_words);
+int qk_accum_reserve(qk_accum *acc, uint64_t max_len); /* grow to common size */
+int qk_accum_export_table(qk_accum *acc, void *d_dst, void *hip_stream);
+int qk_accum_import_table(qk_accum *acc, const void *d_src, uint64_t max_len,
+                          void *hip_stream);
+
+/* In-process multi-GPU: one accumulator per device, one RCCL all-reduce of
+ * the integer tables over xGMI (ncclUint64, ncclSum).  After it every
+ * accumulator holds the global table. */
+int qk_accum_allreduce(qk_accum **accs, int n);
+
+/* Synchronise and copy out: out[0..max_len) in reference layout. */
+int qk_accum_finish(qk_accum *acc, qk_base_info *out, uint64_t cap_positions,
+                    uint64_t *max_len, uint64_t *n_reads);
+
+/* ---- timing hooks (bench.py / kbench) --------------------------------- */
+/* Average duration in ms of the histogram kernel launches recorded since the
+ * last reset, measured with hipEvents on the launch stream. */
+int qk_accum_timing_enable(qk_accum *acc, int on);
+int qk_accum_timing_read(qk_accum *acc, double *total_ms, uint64_t *launches);
+
+/* ---- tuning knobs (env: QUACK_HIP_THREADS / _UNROLL / _TILE) ---------- */
+int qk_accum_configure(qk_accum *acc, int threads_per_wg, int unroll,
+                       int tile_positions, int wgs_per_cu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUACK_HIP_H */

@@ -1,0 +1,286 @@
+// qk_kernels.hip.h — hand-written gfx950 kernels for quack's per-read
+// accumulation loop (reference: read_fastq, quack.c:193-221).
+//
+// Mapping ("chunk owner"): a read segment of a position tile is cut into
+// 8-byte chunks; lane (ri, ch) of a workgroup owns chunk `ch` of the ri-th read
+// of every iteration, i.e. ALWAYS the same 8 positions.  Consequences:
+//   * global loads are one unaligned dwordx2 per array per lane, contiguous
+//     across the lanes of a read (whole 128-B lines are consumed);
+//   * quality scores go to an LDS histogram laid out [byte value][j&3][ch] with
+//     two u16 counters per dword (j>>2 selects the half) and a row stride that
+//     is a multiple of 32 dwords, so the LDS bank of an update is fixed by the
+//     lane's chunk alone — measured SQ_LDS_BANK_CONFLICT ~0.  Per base:
+//     v_bfe (byte -> row) + v_mad_u32_u24 (row -> address) + ds_add_u32;
+//   * base content never touches the LDS in the loop: the owner of a position
+//     keeps SWAR byte counters (valid / T / C / G, 4 positions per VGPR) and
+//     spills them every 255 reads.  A = valid - T - C - G at flush time.
+//     (Measured: LDS *instruction issue*, ~7 cycles per ds_add wave-instruction
+//     per CU, is the binding resource, not the LDS array — two atomics per
+//     base cost 2x one.)
+// Quality rows are raw byte values (& 127); the mapping to quack's 91 score
+// bins is applied once, at flush time (histograms are linear, so re-binning
+// afterwards is exact).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qk {
+
+constexpr int kQRows = 128;            // quality byte & 127
+constexpr int kOutRows = 97;           // quack.c:134-139
+constexpr int kRowContent = 91;
+constexpr int kRowLength = 95;
+constexpr int kRowKmer = 96;
+constexpr uint32_t kMaxReadsPerSlice = 65535; // u16 counters: <=1 hit/read/pos
+
+// Device-side parameter block of one launch.
+struct HistParams {
+  const uint8_t *seq;
+  const uint8_t *qual;
+  const uint64_t *offsets;      // NULL => fixed-length batch
+  unsigned long long *table;    // planar [kOutRows][table_len]
+  uint32_t *first_hit;          // per-read first adapter hit (ADAPT only)
+  const uint32_t *kmer_bits;    // 2^20-bit exact table (ADAPT only)
+  const uint32_t *kmer_filter;  // small LDS-resident pre-filter (ADAPT only)
+  uint64_t n_reads;
+  uint64_t reads_per_slice;     // <= kMaxReadsPerSlice
+  uint32_t read_len;            // fixed-length batches
+  uint32_t table_len;           // positions in `table`
+  uint32_t n_tiles;             // position tiles
+  uint32_t tile_pos;            // positions per tile (multiple of 8)
+  uint32_t ch;                  // chunks per tile = tile_pos / 8
+  uint32_t row_dwords;          // LDS row stride: 4*ch rounded up to 32 banks
+  uint32_t reads_per_iter;      // T / ch
+  uint32_t no_adapters;         // kmers == NULL semantics (quack.c:210,215)
+  uint32_t filter_mask;         // bits in kmer_filter - 1
+};
+
+// one unaligned global_load_dwordx2 (gfx950 runs in unaligned-access mode)
+__device__ __forceinline__ uint2 load8(const uint8_t *p) {
+  uint2 v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+__device__ __forceinline__ void lds_add(uint32_t *lds, uint32_t byte_off,
+                                        uint32_t val) {
+  uint32_t *p = reinterpret_cast<uint32_t *>(
+      reinterpret_cast<char *>(lds) + byte_off);
+  __hip_atomic_fetch_add(p, val, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Per-byte "== K" indicator (0/1 in each byte) on the 5-bit letter key.
+// quack.c:148-150,201 maps letters by (c-65)&~32: T->1, C->2, G->3, every
+// other letter of its defined domain (A..T, a..t) -> 0.  (c & 31) is injective
+// on that domain: T=20, C=3, G=7.  Bytes outside it index lookup[] out of
+// bounds in the reference (undefined); here they alias the letter with the
+// same low five bits.
+__device__ __forceinline__ uint32_t swar_eq(uint32_t w, uint32_t k4) {
+  const uint32_t y = (w & 0x1F1F1F1Fu) ^ k4;   // 0 in matching bytes, <= 0x1F
+  const uint32_t z = y + 0x7F7F7F7Fu;          // bit 7 of a byte <=> byte != 0
+  return ~(z >> 7) & 0x01010101u;
+}
+
+constexpr uint32_t kKeyT = 0x14141414u, kKeyC = 0x03030303u, kKeyG = 0x07070707u;
+
+// LDS image (dwords): quality histogram [128][row_dwords] | base counters
+// [4: valid,T,C,G][8*ch] | length_count [8*ch] | misc[4]
+inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch) { return (4u * ch + 31u) / 32u * 32u; }
+inline size_t hist_lds_bytes(uint32_t ch) {
+  return ((size_t)kQRows * hist_row_dwords(ch) + 5u * 8u * ch + 4u) * sizeof(uint32_t);
+}
+
+// MODE: 0 full; 1 loads only; 2 quality only; 3 bases only (ablation builds
+// used by tools/kbench only; the shim always launches MODE 0).
+template <int T, int U, bool FIXED, int MODE>
+__global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t CH = p.ch;
+  const uint32_t tile = blockIdx.x % p.n_tiles;
+  const uint32_t slice = blockIdx.x / p.n_tiles;
+  const uint32_t P0 = tile * p.tile_pos;
+  const uint32_t RD = p.row_dwords;
+  const uint32_t TP = 8u * CH;  // == p.tile_pos
+  const uint32_t hist_words = kQRows * RD;
+  uint32_t *lds_base = lds + hist_words;  // [4][TP]
+  uint32_t *lds_len = lds_base + 4u * TP;
+  uint32_t *lds_misc = lds_len + TP;
+
+  for (uint32_t i = tid; i < hist_words + 5u * TP + 4u; i += T) lds[i] = 0;
+  __syncthreads();
+
+  const uint32_t ri = tid / CH;
+  const uint32_t ch = tid - ri * CH;
+  const uint32_t RW = p.reads_per_iter;
+  const bool lane_on = ri < RW;
+  const uint32_t cpos = P0 + 8u * ch;   // first position of the owned chunk
+  const uint32_t row_bytes = 4u * RD;   // a multiple of 128 B: bank == column
+  uint32_t qcol[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) qcol[jj] = (jj * CH + ch) * 4u;
+  const uint32_t one_lo = 1u, one_hi = 65536u;
+
+  const uint64_t r_begin = (uint64_t)slice * p.reads_per_slice;
+  uint64_t r_end = r_begin + p.reads_per_slice;
+  if (r_end > p.n_reads) r_end = p.n_reads;
+
+  uint32_t n_gt10 = 0;   // reads longer than 10 (kmers==NULL path, quack.c:215)
+  uint32_t keep = 0;     // MODE 1 only
+  // SWAR byte counters for the 8 owned positions: [0] positions 0-3, [1] 4-7
+  uint32_t acc_v[2] = {0, 0}, acc_t[2] = {0, 0}, acc_c[2] = {0, 0}, acc_g[2] = {0, 0};
+  uint32_t since_spill = 0;
+
+  auto spill = [&]() {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint32_t off = (8u * ch + 4u * d + b) * 4u;
+        const uint32_t v = (acc_v[d] >> (8 * b)) & 0xFFu;
+        if (v == 0) continue;  // nothing valid => no T/C/G either
+        lds_add(lds_base, off, v);
+        const uint32_t t = (acc_t[d] >> (8 * b)) & 0xFFu;
+        const uint32_t c = (acc_c[d] >> (8 * b)) & 0xFFu;
+        const uint32_t g = (acc_g[d] >> (8 * b)) & 0xFFu;
+        if (t) lds_add(lds_base, off + 4u * TP, t);
+        if (c) lds_add(lds_base, off + 8u * TP, c);
+        if (g) lds_add(lds_base, off + 12u * TP, g);
+      }
+      acc_v[d] = acc_t[d] = acc_c[d] = acc_g[d] = 0;
+    }
+    since_spill = 0;
+  };
+
+  for (uint64_t r0 = r_begin; r0 < r_end; r0 += (uint64_t)RW * U) {
+    uint2 q[U], s[U];
+    uint32_t nv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t r = r0 + (uint64_t)u * RW + ri;
+      const bool ok = lane_on && r < r_end;
+      uint64_t start;
+      uint32_t len;
+      if (FIXED) {
+        start = r * p.read_len;
+        len = p.read_len;
+      } else {
+        const uint64_t rr = ok ? r : r_begin;  // r_begin < n_reads inside the loop
+        start = p.offsets[rr];
+        len = (uint32_t)(p.offsets[rr + 1] - start);
+      }
+      uint32_t n = (ok && len > cpos) ? len - cpos : 0u;
+      n = n > 8u ? 8u : n;
+      nv[u] = n;
+      const uint64_t a = n ? start + cpos : 0;
+      q[u] = load8(p.qual + a);
+      s[u] = load8(p.seq + a);
+      if (!FIXED) {
+        // length_count / kmers==NULL bookkeeping by the owner of chunk 0
+        if (ok && ch == 0 && tile == 0) {
+          n_gt10 += len > 10u ? 1u : 0u;
+          if (len != 0) {
+            const uint32_t lp = len - 1u;
+            if (lp < TP)
+              lds_add(lds_len, lp * 4u, 1u);
+            else
+              atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + lp], 1ull);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // bytes past the end of the read -> 0xFF: quality row 127 is discarded
+      // at flush time, and 0xFF & 31 matches none of T/C/G.
+      const uint32_t n = nv[u];
+      const uint32_t m0 = n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n));
+      const uint32_t m1 = n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu
+                                                   : (0xFFFFFFFFu << (8u * (n - 4u))));
+      const uint32_t mk[2] = {m0, m1};
+      const uint32_t qw[2] = {q[u].x | m0, q[u].y | m1};
+      const uint32_t sw[2] = {s[u].x | m0, s[u].y | m1};
+      if (MODE == 1) {
+        keep ^= qw[0] ^ qw[1] ^ sw[0] ^ sw[1];
+        continue;
+      }
+      if (MODE == 0 || MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t b = __builtin_amdgcn_ubfe(qw[j >> 2], 8 * (j & 3), 7);
+          lds_add(lds, __umul24(b, row_bytes) + qcol[j & 3], (j >> 2) ? one_hi : one_lo);
+        }
+      }
+      if (MODE == 0 || MODE == 3) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          acc_v[d] += ~mk[d] & 0x01010101u;
+          acc_t[d] += swar_eq(sw[d], kKeyT);
+          acc_c[d] += swar_eq(sw[d], kKeyC);
+          acc_g[d] += swar_eq(sw[d], kKeyG);
+        }
+      }
+    }
+    if (MODE == 0 || MODE == 3) {
+      since_spill += U;
+      if (since_spill + U > 255u) spill();   // byte counters hold <= 255
+    }
+  }
+  if (MODE == 0 || MODE == 3) spill();
+
+  if (MODE == 1) {
+    if (keep == 0x12345678u) lds[0] = keep;
+  }
+  if (!FIXED && n_gt10) lds_add(lds_misc, 0, n_gt10);
+  __syncthreads();
+
+  // ---- flush: LDS -> planar u64 table; zero counters are skipped.  One wave
+  // per quality row, lanes along positions (contiguous 512-B atomics).
+  const uint64_t TL = p.table_len;
+  const uint32_t wave = tid >> 6, lane = tid & 63u;
+  for (uint32_t row = 33u + wave; row <= 123u; row += T / 64) {  // quack.c:203: bin = byte - 33
+    for (uint32_t pp = lane; pp < TP; pp += 64u) {
+      const uint32_t c8 = pp >> 3, j = pp & 7u;
+      const uint32_t w = lds[row * RD + (j & 3u) * CH + c8];
+      const uint32_t c = (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
+      const uint32_t pos = P0 + pp;
+      if (c != 0 && pos < p.table_len)
+        atomicAdd(&p.table[(uint64_t)(row - 33u) * TL + pos], (unsigned long long)c);
+    }
+  }
+  for (uint32_t pp = tid; pp < TP; pp += T) {
+    const uint32_t v = lds_base[pp];
+    const uint32_t pos = P0 + pp;
+    if (v == 0 || pos >= p.table_len) continue;
+    const uint32_t t = lds_base[TP + pp], c = lds_base[2u * TP + pp], g = lds_base[3u * TP + pp];
+    unsigned long long *row0 = &p.table[(uint64_t)kRowContent * TL + pos];
+    const uint32_t a = v - t - c - g;                     // content[] order: A,T,C,G (quack.c:150)
+    if (a) atomicAdd(row0, (unsigned long long)a);
+    if (t) atomicAdd(row0 + TL, (unsigned long long)t);
+    if (c) atomicAdd(row0 + 2u * TL, (unsigned long long)c);
+    if (g) atomicAdd(row0 + 3u * TL, (unsigned long long)g);
+  }
+  if (tile == 0) {
+    if (FIXED) {
+      if (tid == 0 && r_end > r_begin) {
+        const unsigned long long n = r_end - r_begin;
+        if (p.read_len != 0)
+          atomicAdd(&p.table[(uint64_t)kRowLength * TL + p.read_len - 1u], n);   // quack.c:219
+        if (p.no_adapters && p.read_len > 10u)
+          atomicAdd(&p.table[(uint64_t)kRowKmer * TL + 10u], n);                 // quack.c:215-217, i == 10
+      }
+    } else {
+      for (uint32_t pp = tid; pp < TP; pp += T) {
+        const uint32_t c = lds_len[pp];
+        if (c != 0 && pp < p.table_len)
+          atomicAdd(&p.table[(uint64_t)kRowLength * TL + pp], (unsigned long long)c);
+      }
+      if (tid == 0 && p.no_adapters && lds_misc[0] != 0)
+        atomicAdd(&p.table[(uint64_t)kRowKmer * TL + 10u],
+                  (unsigned long long)lds_misc[0]);
+    }
+  }
+}
+
+}  // namespace qk

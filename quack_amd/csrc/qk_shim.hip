@@ -1,0 +1,728 @@
+// qk_shim.hip — implementation of include/quack_hip.h (libquack_hip.so).
+//
+// One qk_accum == the state of one read_fastq() call (quack.c:180-228) kept
+// resident on one MI355X: a planar u64 counter table [97][table_len], two
+// pinned host batch slots with matching device slots (hipHostMalloc +
+// hipMemcpyAsync, one HIP stream per slot so the copy of batch k+1 overlaps
+// the kernels of batch k), and the adapter 10-mer tables.
+// No CPU fallback lives here: every failure is reported to the caller.
+#include "quack_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "qk_adapter_kernels.hip.h"
+#include "qk_kernels.hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define QK_HIP(call)                                                        \
+  do {                                                                      \
+    hipError_t e_ = (call);                                                 \
+    if (e_ != hipSuccess)                                                   \
+      return fail(QK_EHIP, "%s failed: %s (%s:%d)", #call,                  \
+                  hipGetErrorString(e_), __FILE__, __LINE__);               \
+  } while (0)
+
+uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+struct Slot {
+  uint8_t *h_seq = nullptr, *h_qual = nullptr;
+  uint64_t *h_off = nullptr;
+  uint8_t *d_seq = nullptr, *d_qual = nullptr;
+  uint64_t *d_off = nullptr;
+  uint32_t *d_hit = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  bool busy = false;
+};
+
+struct TimedLaunch {
+  hipEvent_t t0, t1;
+};
+
+}  // namespace
+
+struct qk_accum {
+  int device = 0;
+  int n_cu = 256;
+  // counter table: planar [QK_N_ROWS][table_len] u64 + 1 trailing word
+  unsigned long long *d_table = nullptr;
+  uint64_t table_len = 0;
+  uint64_t max_len = 0;
+  uint64_t n_reads = 0;
+  // adapters
+  bool adapters = false;
+  uint32_t *d_kmer_bits = nullptr;
+  uint32_t *d_kmer_filter = nullptr;
+  uint32_t filter_bits = 0;
+  // pipeline
+  Slot slot[2];
+  int next_slot = 0;
+  int held_slot = -1;
+  uint64_t cap_bytes = 0, cap_reads = 0;
+  hipStream_t stream = nullptr;     // own stream for device-resident submits
+  bool foreign_stream_used = false;
+  uint32_t *d_hit_scratch = nullptr;  // first-hit buffer for device submits
+  uint64_t hit_scratch_reads = 0;
+  // tuning
+  int threads = 1024, unroll = 4, tile = 192, wgs_per_cu = 2;
+  // timing
+  bool timing = false;
+  std::vector<TimedLaunch> timed;
+  std::vector<hipEvent_t> event_pool;
+  double timing_ms = 0;
+  uint64_t timing_launches = 0;
+};
+
+namespace {
+
+int ensure_slots(qk_accum *a) {
+  if (a->slot[0].h_seq) return QK_OK;
+  const uint64_t mb = (uint64_t)env_int("QUACK_HIP_BATCH_MB", 64);
+  a->cap_bytes = mb << 20;
+  a->cap_reads = a->cap_bytes / 32 + 1024;  // >= one read per 32 bytes
+  for (int i = 0; i < 2; ++i) {
+    Slot &s = a->slot[i];
+    QK_HIP(hipHostMalloc((void **)&s.h_seq, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
+    QK_HIP(hipHostMalloc((void **)&s.h_qual, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
+    QK_HIP(hipHostMalloc((void **)&s.h_off, (a->cap_reads + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    QK_HIP(hipMalloc((void **)&s.d_seq, a->cap_bytes + QK_TAIL_SLACK));
+    QK_HIP(hipMalloc((void **)&s.d_qual, a->cap_bytes + QK_TAIL_SLACK));
+    QK_HIP(hipMalloc((void **)&s.d_off, (a->cap_reads + 1) * sizeof(uint64_t)));
+    if (a->adapters) QK_HIP(hipMalloc((void **)&s.d_hit, a->cap_reads * sizeof(uint32_t)));
+    QK_HIP(hipMemset(s.d_seq + a->cap_bytes, 0, QK_TAIL_SLACK));
+    QK_HIP(hipMemset(s.d_qual + a->cap_bytes, 0, QK_TAIL_SLACK));
+    QK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    QK_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  }
+  return QK_OK;
+}
+
+// Grow the planar table so that it holds `need` positions.  Rare (once or
+// twice per file, like the realloc at quack.c:194-198), so it synchronises.
+int grow_table(qk_accum *a, uint64_t need) {
+  if (need <= a->table_len) return QK_OK;
+  QK_HIP(hipDeviceSynchronize());
+  uint64_t nl = std::max<uint64_t>(need, a->table_len * 2);
+  nl = round_up(std::max<uint64_t>(nl, 64), 64);
+  unsigned long long *nt = nullptr;
+  const size_t words = (size_t)QK_N_ROWS * nl + 1;
+  QK_HIP(hipMalloc((void **)&nt, words * sizeof(unsigned long long)));
+  QK_HIP(hipMemset(nt, 0, words * sizeof(unsigned long long)));
+  if (a->d_table) {
+    QK_HIP(hipMemcpy2D(nt, nl * 8, a->d_table, a->table_len * 8,
+                       a->table_len * 8, QK_N_ROWS, hipMemcpyDeviceToDevice));
+    QK_HIP(hipFree(a->d_table));
+  }
+  a->d_table = nt;
+  a->table_len = nl;
+  return QK_OK;
+}
+
+struct Plan {
+  uint32_t n_tiles, tile_pos, ch, rw;
+  uint64_t reads_per_slice, n_slices;
+};
+
+int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, Plan *pl) {
+  const uint32_t T = (uint32_t)a->threads, U = (uint32_t)a->unroll;
+  uint32_t max_tile = (uint32_t)a->tile;
+  max_tile = std::max<uint32_t>(8, max_tile / 8 * 8);
+  if (max_tile / 8 > T) max_tile = T * 8;
+  uint32_t n_tiles = (max_len + max_tile - 1) / max_tile;
+  if (n_tiles == 0) n_tiles = 1;
+  uint32_t tile_pos = (uint32_t)round_up((max_len + n_tiles - 1) / n_tiles, 8);
+  if (tile_pos == 0) tile_pos = 8;
+  pl->n_tiles = n_tiles;
+  pl->tile_pos = tile_pos;
+  pl->ch = tile_pos / 8;
+  pl->rw = T / pl->ch;
+  const uint64_t step = (uint64_t)pl->rw * U;
+  uint64_t target = (uint64_t)a->n_cu * a->wgs_per_cu;
+  uint64_t n_slices = std::max<uint64_t>(1, target / n_tiles);
+  uint64_t rps = (n_reads + n_slices - 1) / n_slices;
+  rps = round_up(std::max<uint64_t>(rps, 1), step);
+  // u16 LDS counters: a workgroup may see at most 65535 reads (interleaved
+  // slices can get one extra group, hence the margin of `step`)
+  if (step * 2 > qk::kMaxReadsPerSlice) return fail(QK_EINVAL, "tile too wide for u16 counters");
+  const uint64_t cap = (qk::kMaxReadsPerSlice - step) / step * step;
+  if (rps > cap) rps = cap;
+  pl->reads_per_slice = rps;
+  pl->n_slices = (n_reads + rps - 1) / rps;
+  return QK_OK;
+}
+
+template <int T, int U>
+int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, dim3 grid,
+                   size_t lds, hipStream_t st) {
+  void (*k)(const qk::HistParams) = nullptr;
+  if (fixed) {
+    switch (mode) {
+      case 0: k = qk::hist_kernel<T, U, true, 0>; break;
+#ifdef QK_ABLATION
+      case 1: k = qk::hist_kernel<T, U, true, 1>; break;
+      case 2: k = qk::hist_kernel<T, U, true, 2>; break;
+      case 3: k = qk::hist_kernel<T, U, true, 3>; break;
+#endif
+    }
+  } else {
+    if (mode == 0) k = qk::hist_kernel<T, U, false, 0>;
+  }
+  if (!k) return fail(QK_EINVAL, "kernel variant not built (mode %d)", mode);
+  QK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, grid, dim3(T), lds, st, hp);
+  QK_HIP(hipGetLastError());
+  return QK_OK;
+}
+
+int launch_hist(qk_accum *a, const qk::HistParams &hp, bool fixed, int mode,
+                uint64_t n_blocks, hipStream_t st) {
+  const size_t lds = qk::hist_lds_bytes(hp.ch);
+  if (lds > 160 * 1024) return fail(QK_EINVAL, "LDS tile too large (%zu bytes)", lds);
+  dim3 grid((unsigned)n_blocks);
+#define QK_TU(TT, UU) \
+  if (a->threads == TT && a->unroll == UU) return launch_hist_tu<TT, UU>(hp, fixed, mode, grid, lds, st);
+  QK_TU(1024, 4) QK_TU(1024, 2) QK_TU(1024, 1)
+  QK_TU(512, 4) QK_TU(512, 2) QK_TU(512, 1)
+  QK_TU(256, 4) QK_TU(256, 2)
+#undef QK_TU
+  return fail(QK_EINVAL, "unsupported threads/unroll %d/%d", a->threads, a->unroll);
+}
+
+hipEvent_t get_event(qk_accum *a) {
+  if (!a->event_pool.empty()) {
+    hipEvent_t e = a->event_pool.back();
+    a->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+int g_ablation_mode = 0;  // set through qk_debug_set_mode (kbench only)
+
+// Enqueue the kernels of one device-resident batch on `st`.
+int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
+                  const uint64_t *d_off, uint32_t *d_hit, uint64_t n_reads,
+                  uint32_t max_len, hipStream_t st) {
+  if (n_reads == 0) return QK_OK;
+  if (n_reads > 0xFFFFFFF0ull) return fail(QK_EINVAL, "batch too large");
+  int rc = grow_table(a, std::max<uint64_t>(max_len, 11));
+  if (rc) return rc;
+  if (max_len == 0) {  // only empty reads: they count as sequences, nothing else
+    a->n_reads += n_reads;
+    return QK_OK;
+  }
+  Plan pl;
+  rc = make_plan(a, n_reads, max_len, &pl);
+  if (rc) return rc;
+  qk::HistParams hp{};
+  hp.seq = d_seq;
+  hp.qual = d_qual;
+  hp.offsets = d_off;
+  hp.table = a->d_table;
+  hp.first_hit = d_hit;
+  hp.kmer_bits = a->d_kmer_bits;
+  hp.kmer_filter = a->d_kmer_filter;
+  hp.filter_mask = a->filter_bits ? a->filter_bits - 1 : 0;
+  hp.n_reads = n_reads;
+  hp.reads_per_slice = pl.reads_per_slice;
+  hp.read_len = d_off ? 0 : max_len;
+  hp.table_len = (uint32_t)a->table_len;
+  hp.n_tiles = pl.n_tiles;
+  hp.tile_pos = pl.tile_pos;
+  hp.ch = pl.ch;
+  hp.reads_per_iter = pl.rw;
+  hp.row_dwords = qk::hist_row_dwords(pl.ch);
+  hp.no_adapters = a->adapters ? 0 : 1;
+
+  TimedLaunch tl{};
+  if (a->timing) {
+    tl.t0 = get_event(a);
+    tl.t1 = get_event(a);
+    if (!tl.t0 || !tl.t1) return fail(QK_EHIP, "hipEventCreate failed");
+    QK_HIP(hipEventRecord(tl.t0, st));
+  }
+  rc = launch_hist(a, hp, d_off == nullptr, g_ablation_mode,
+                   pl.n_slices * pl.n_tiles, st);
+  if (rc) return rc;
+  if (a->timing) {
+    QK_HIP(hipEventRecord(tl.t1, st));
+    a->timed.push_back(tl);
+  }
+  if (a->adapters) {
+    rc = qk::launch_adapter_scan(hp, a->n_cu, st);
+    if (rc) return fail(QK_EHIP, "adapter kernels failed: %s", hipGetErrorString((hipError_t)rc));
+  }
+  a->n_reads += n_reads;
+  a->max_len = std::max<uint64_t>(a->max_len, max_len);
+  return QK_OK;
+}
+
+int drain_timing(qk_accum *a) {
+  for (auto &tl : a->timed) {
+    float ms = 0;
+    QK_HIP(hipEventSynchronize(tl.t1));
+    QK_HIP(hipEventElapsedTime(&ms, tl.t0, tl.t1));
+    a->timing_ms += ms;
+    a->timing_launches += 1;
+    a->event_pool.push_back(tl.t0);
+    a->event_pool.push_back(tl.t1);
+  }
+  a->timed.clear();
+  return QK_OK;
+}
+
+int set_device(const qk_accum *a) {
+  QK_HIP(hipSetDevice(a->device));
+  return QK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *qk_last_error(void) { return g_err; }
+const char *qk_version(void) { return "quack_hip 0.1 (gfx950)"; }
+
+int qk_device_count(int *count) {
+  if (!count) return fail(QK_EINVAL, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(QK_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return QK_OK;
+}
+
+int qk_debug_set_mode(int mode) {
+  g_ablation_mode = mode;
+  return QK_OK;
+}
+
+int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
+                    uint64_t max_len_hint) {
+  if (!out) return fail(QK_EINVAL, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(QK_ENODEV, "no HIP device available (the accumulation path has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(QK_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+  qk_accum *a = new (std::nothrow) qk_accum();
+  if (!a) return fail(QK_ENOMEM, "out of memory");
+  a->device = device;
+  int rc = QK_OK;
+  do {
+    if ((rc = set_device(a))) break;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+      rc = fail(QK_EHIP, "hipGetDeviceProperties failed");
+      break;
+    }
+    a->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    a->threads = env_int("QUACK_HIP_THREADS", a->threads);
+    a->unroll = env_int("QUACK_HIP_UNROLL", a->unroll);
+    a->tile = env_int("QUACK_HIP_TILE", a->tile);
+    a->wgs_per_cu = env_int("QUACK_HIP_WGS_PER_CU", a->wgs_per_cu);
+    if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
+      rc = fail(QK_EHIP, "hipStreamCreate failed");
+      break;
+    }
+    if (kmer_bitset) {
+      a->adapters = true;
+      rc = qk::upload_kmer_tables(kmer_bitset, &a->d_kmer_bits, &a->d_kmer_filter, &a->filter_bits);
+      if (rc) {
+        rc = fail(QK_EHIP, "uploading adapter tables failed: %s", hipGetErrorString((hipError_t)rc));
+        break;
+      }
+    }
+    if ((rc = grow_table(a, std::max<uint64_t>(max_len_hint, 64)))) break;
+  } while (0);
+  if (rc) {
+    qk_accum_destroy(a);
+    return rc;
+  }
+  *out = a;
+  return QK_OK;
+}
+
+void qk_accum_destroy(qk_accum *a) {
+  if (!a) return;
+  (void)hipSetDevice(a->device);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < 2; ++i) {
+    Slot &s = a->slot[i];
+    if (s.h_seq) (void)hipHostFree(s.h_seq);
+    if (s.h_qual) (void)hipHostFree(s.h_qual);
+    if (s.h_off) (void)hipHostFree(s.h_off);
+    if (s.d_seq) (void)hipFree(s.d_seq);
+    if (s.d_qual) (void)hipFree(s.d_qual);
+    if (s.d_off) (void)hipFree(s.d_off);
+    if (s.d_hit) (void)hipFree(s.d_hit);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  for (auto &tl : a->timed) {
+    (void)hipEventDestroy(tl.t0);
+    (void)hipEventDestroy(tl.t1);
+  }
+  for (auto e : a->event_pool) (void)hipEventDestroy(e);
+  if (a->d_hit_scratch) (void)hipFree(a->d_hit_scratch);
+  if (a->d_kmer_bits) (void)hipFree(a->d_kmer_bits);
+  if (a->d_kmer_filter) (void)hipFree(a->d_kmer_filter);
+  if (a->d_table) (void)hipFree(a->d_table);
+  if (a->stream) (void)hipStreamDestroy(a->stream);
+  delete a;
+}
+
+int qk_accum_configure(qk_accum *a, int threads, int unroll, int tile, int wgs_per_cu) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  if (threads > 0) a->threads = threads;
+  if (unroll > 0) a->unroll = unroll;
+  if (tile > 0) a->tile = tile;
+  if (wgs_per_cu > 0) a->wgs_per_cu = wgs_per_cu;
+  return QK_OK;
+}
+
+int qk_accum_acquire(qk_accum *a, uint8_t **seq, uint8_t **qual, uint64_t **offsets,
+                     uint64_t *cap_bytes, uint64_t *cap_reads) {
+  if (!a || !seq || !qual || !offsets) return fail(QK_EINVAL, "NULL argument");
+  if (a->held_slot >= 0) return fail(QK_ESTATE, "a batch is already acquired");
+  int rc = set_device(a);
+  if (rc) return rc;
+  if ((rc = ensure_slots(a))) return rc;
+  Slot &s = a->slot[a->next_slot];
+  if (s.busy) {
+    QK_HIP(hipEventSynchronize(s.done));
+    s.busy = false;
+  }
+  a->held_slot = a->next_slot;
+  *seq = s.h_seq;
+  *qual = s.h_qual;
+  *offsets = s.h_off;
+  if (cap_bytes) *cap_bytes = a->cap_bytes;
+  if (cap_reads) *cap_reads = a->cap_reads;
+  return QK_OK;
+}
+
+int qk_accum_commit(qk_accum *a, uint64_t n_reads, uint64_t total, int offsets_used,
+                    uint32_t read_len) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  if (a->held_slot < 0) return fail(QK_ESTATE, "no batch acquired");
+  Slot &s = a->slot[a->held_slot];
+  if (total > a->cap_bytes || n_reads > a->cap_reads)
+    return fail(QK_EINVAL, "batch exceeds slot capacity");
+  int rc = set_device(a);
+  if (rc) return rc;
+  uint32_t max_len = read_len;
+  if (offsets_used) {
+    if (s.h_off[0] != 0 || s.h_off[n_reads] != total)
+      return fail(QK_EINVAL, "offsets[0] must be 0 and offsets[n] the byte total");
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+      if (s.h_off[i + 1] < s.h_off[i]) return fail(QK_EINVAL, "offsets not monotonic at read %llu", (unsigned long long)i);
+      m = std::max(m, s.h_off[i + 1] - s.h_off[i]);
+    }
+    if (m > 0xFFFFFFF0ull) return fail(QK_EINVAL, "read too long");
+    max_len = (uint32_t)m;
+  } else if ((uint64_t)read_len * n_reads != total) {
+    return fail(QK_EINVAL, "fixed batch: n_reads*read_len != total");
+  }
+  a->held_slot = -1;
+  a->next_slot ^= 1;
+  if (n_reads == 0) return QK_OK;
+  // grow before enqueueing copies so that the (synchronising) growth cannot
+  // race with this slot's stream
+  if ((rc = grow_table(a, std::max<uint64_t>(max_len, 11)))) return rc;
+  // pad the tail so that the 8-byte chunk loads past the last read are defined
+  memset(s.h_seq + total, 0, QK_TAIL_SLACK);
+  memset(s.h_qual + total, 0, QK_TAIL_SLACK);
+  QK_HIP(hipMemcpyAsync(s.d_seq, s.h_seq, total + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
+  QK_HIP(hipMemcpyAsync(s.d_qual, s.h_qual, total + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
+  if (offsets_used)
+    QK_HIP(hipMemcpyAsync(s.d_off, s.h_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+  rc = enqueue_batch(a, s.d_seq, s.d_qual, offsets_used ? s.d_off : nullptr, s.d_hit,
+                     n_reads, max_len, s.stream);
+  if (rc) return rc;
+  QK_HIP(hipEventRecord(s.done, s.stream));
+  s.busy = true;
+  return QK_OK;
+}
+
+int qk_accum_submit(qk_accum *a, const uint8_t *seq, const uint8_t *qual,
+                    const uint64_t *offsets, uint64_t n_reads) {
+  if (!a || !offsets || (n_reads && (!seq || !qual))) return fail(QK_EINVAL, "NULL argument");
+  uint64_t i = 0;
+  while (i < n_reads) {
+    uint8_t *hs, *hq;
+    uint64_t *ho, capb, capr;
+    int rc = qk_accum_acquire(a, &hs, &hq, &ho, &capb, &capr);
+    if (rc) return rc;
+    const uint64_t base = offsets[i];
+    uint64_t j = i;
+    while (j < n_reads && j - i < capr && offsets[j + 1] - base <= capb) ++j;
+    if (j == i) {
+      a->held_slot = -1;
+      return fail(QK_EINVAL, "read %llu (%llu bytes) exceeds the batch slot; raise QUACK_HIP_BATCH_MB",
+                  (unsigned long long)i, (unsigned long long)(offsets[i + 1] - base));
+    }
+    const uint64_t bytes = offsets[j] - base;
+    memcpy(hs, seq + base, bytes);
+    memcpy(hq, qual + base, bytes);
+    for (uint64_t k = i; k <= j; ++k) ho[k - i] = offsets[k] - base;
+    if ((rc = qk_accum_commit(a, j - i, bytes, 1, 0))) return rc;
+    i = j;
+  }
+  return QK_OK;
+}
+
+int qk_accum_submit_fixed(qk_accum *a, const uint8_t *seq, const uint8_t *qual,
+                          uint32_t read_len, uint64_t n_reads) {
+  if (!a || (n_reads && read_len && (!seq || !qual))) return fail(QK_EINVAL, "NULL argument");
+  if (read_len == 0) {
+    a->n_reads += n_reads;
+    return QK_OK;
+  }
+  uint64_t i = 0;
+  while (i < n_reads) {
+    uint8_t *hs, *hq;
+    uint64_t *ho, capb, capr;
+    int rc = qk_accum_acquire(a, &hs, &hq, &ho, &capb, &capr);
+    if (rc) return rc;
+    uint64_t n = std::min<uint64_t>(n_reads - i, capb / read_len);
+    if (n == 0) {
+      a->held_slot = -1;
+      return fail(QK_EINVAL, "read_len exceeds the batch slot");
+    }
+    memcpy(hs, seq + i * read_len, n * read_len);
+    memcpy(hq, qual + i * read_len, n * read_len);
+    if ((rc = qk_accum_commit(a, n, n * read_len, 0, read_len))) return rc;
+    i += n;
+  }
+  return QK_OK;
+}
+
+int qk_accum_submit_device(qk_accum *a, const void *d_seq, const void *d_qual,
+                           const void *d_offsets, uint64_t n_reads, uint64_t total_bytes,
+                           uint32_t max_len, void *hip_stream) {
+  if (!a || (n_reads && max_len && (!d_seq || !d_qual))) return fail(QK_EINVAL, "NULL argument");
+  (void)total_bytes;
+  int rc = set_device(a);
+  if (rc) return rc;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : a->stream;
+  if (hip_stream) a->foreign_stream_used = true;
+  uint32_t *d_hit = nullptr;
+  if (a->adapters) {
+    if (a->hit_scratch_reads < n_reads) {
+      QK_HIP(hipDeviceSynchronize());
+      if (a->d_hit_scratch) QK_HIP(hipFree(a->d_hit_scratch));
+      a->d_hit_scratch = nullptr;
+      QK_HIP(hipMalloc((void **)&a->d_hit_scratch, n_reads * sizeof(uint32_t)));
+      a->hit_scratch_reads = n_reads;
+    }
+    d_hit = a->d_hit_scratch;
+  }
+  return enqueue_batch(a, (const uint8_t *)d_seq, (const uint8_t *)d_qual,
+                       (const uint64_t *)d_offsets, d_hit, n_reads, max_len, st);
+}
+
+int qk_accum_sync(qk_accum *a) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  int rc = set_device(a);
+  if (rc) return rc;
+  if (a->foreign_stream_used) {
+    QK_HIP(hipDeviceSynchronize());
+  } else {
+    QK_HIP(hipStreamSynchronize(a->stream));
+    for (int i = 0; i < 2; ++i)
+      if (a->slot[i].stream) QK_HIP(hipStreamSynchronize(a->slot[i].stream));
+  }
+  for (int i = 0; i < 2; ++i) a->slot[i].busy = false;
+  return drain_timing(a);
+}
+
+int qk_accum_stats(qk_accum *a, uint64_t *max_len, uint64_t *n_reads) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  if (max_len) *max_len = a->max_len;
+  if (n_reads) *n_reads = a->n_reads;
+  return QK_OK;
+}
+
+int qk_accum_table_words(qk_accum *a, uint64_t *n_words) {
+  if (!a || !n_words) return fail(QK_EINVAL, "NULL argument");
+  *n_words = (uint64_t)QK_N_ROWS * a->table_len + 1;
+  return QK_OK;
+}
+
+int qk_accum_reserve(qk_accum *a, uint64_t max_len) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  int rc = set_device(a);
+  if (rc) return rc;
+  return grow_table(a, max_len);
+}
+
+int qk_accum_export_table(qk_accum *a, void *d_dst, void *hip_stream) {
+  if (!a || !d_dst) return fail(QK_EINVAL, "NULL argument");
+  int rc = qk_accum_sync(a);
+  if (rc) return rc;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : a->stream;
+  const size_t words = (size_t)QK_N_ROWS * a->table_len;
+  unsigned long long n = a->n_reads;
+  QK_HIP(hipMemcpyAsync(a->d_table + words, &n, 8, hipMemcpyHostToDevice, st));
+  QK_HIP(hipMemcpyAsync(d_dst, a->d_table, (words + 1) * 8, hipMemcpyDeviceToDevice, st));
+  QK_HIP(hipStreamSynchronize(st));
+  return QK_OK;
+}
+
+int qk_accum_import_table(qk_accum *a, const void *d_src, uint64_t max_len, void *hip_stream) {
+  if (!a || !d_src) return fail(QK_EINVAL, "NULL argument");
+  int rc = qk_accum_sync(a);
+  if (rc) return rc;
+  if (max_len > a->table_len) return fail(QK_EINVAL, "max_len exceeds the table; call qk_accum_reserve first");
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : a->stream;
+  const size_t words = (size_t)QK_N_ROWS * a->table_len;
+  unsigned long long n = 0;
+  QK_HIP(hipMemcpyAsync(a->d_table, d_src, (words + 1) * 8, hipMemcpyDeviceToDevice, st));
+  QK_HIP(hipMemcpyAsync(&n, a->d_table + words, 8, hipMemcpyDeviceToHost, st));
+  QK_HIP(hipStreamSynchronize(st));
+  a->n_reads = n;
+  a->max_len = max_len;
+  return QK_OK;
+}
+
+// ---- RCCL (loaded on first use; libquack_hip.so itself does not link it) ----
+typedef struct ncclComm *ncclComm_t;
+typedef int (*fn_CommInitAll)(ncclComm_t *, int, const int *);
+typedef int (*fn_AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
+typedef int (*fn_Void)(void);
+typedef int (*fn_CommDestroy)(ncclComm_t);
+typedef const char *(*fn_ErrStr)(int);
+
+int qk_accum_allreduce(qk_accum **accs, int n) {
+  if (!accs || n <= 0) return fail(QK_EINVAL, "bad arguments");
+  for (int i = 0; i < n; ++i)
+    if (!accs[i]) return fail(QK_EINVAL, "accs[%d] is NULL", i);
+  // common geometry: the longest read seen by any shard (ncclMax on one word
+  // in a multi-process job; here the host already knows every shard)
+  uint64_t max_len = 0, table_len = 0, total_reads = 0;
+  for (int i = 0; i < n; ++i) {
+    int rc = qk_accum_sync(accs[i]);
+    if (rc) return rc;
+    max_len = std::max(max_len, accs[i]->max_len);
+    table_len = std::max(table_len, accs[i]->table_len);
+    total_reads += accs[i]->n_reads;
+  }
+  for (int i = 0; i < n; ++i) {
+    int rc = set_device(accs[i]);
+    if (rc) return rc;
+    if ((rc = grow_table(accs[i], table_len))) return rc;
+    if (accs[i]->table_len != table_len) return fail(QK_ESTATE, "table sizes diverged");
+  }
+  if (n > 1) {
+    static void *lib = nullptr;
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(QK_ERCCL, "cannot load librccl.so: %s", dlerror());
+    fn_CommInitAll init = (fn_CommInitAll)dlsym(lib, "ncclCommInitAll");
+    fn_AllReduce allreduce = (fn_AllReduce)dlsym(lib, "ncclAllReduce");
+    fn_Void gstart = (fn_Void)dlsym(lib, "ncclGroupStart");
+    fn_Void gend = (fn_Void)dlsym(lib, "ncclGroupEnd");
+    fn_CommDestroy cdestroy = (fn_CommDestroy)dlsym(lib, "ncclCommDestroy");
+    fn_ErrStr errstr = (fn_ErrStr)dlsym(lib, "ncclGetErrorString");
+    if (!init || !allreduce || !gstart || !gend || !cdestroy || !errstr)
+      return fail(QK_ERCCL, "librccl.so lacks a required symbol");
+    std::vector<ncclComm_t> comms(n);
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) devs[i] = accs[i]->device;
+    int e = init(comms.data(), n, devs.data());
+    if (e) return fail(QK_ERCCL, "ncclCommInitAll: %s", errstr(e));
+    const size_t words = (size_t)QK_N_ROWS * table_len;
+    const int kNcclUint64 = 5, kNcclSum = 0;  // rccl.h: ncclUint64 = 5, ncclSum = 0
+    e = gstart();
+    for (int i = 0; i < n && !e; ++i) {
+      (void)hipSetDevice(accs[i]->device);
+      e = allreduce(accs[i]->d_table, accs[i]->d_table, words, kNcclUint64, kNcclSum, comms[i], accs[i]->stream);
+    }
+    int e2 = gend();
+    if (!e) e = e2;
+    for (int i = 0; i < n; ++i) {
+      (void)hipSetDevice(accs[i]->device);
+      (void)hipStreamSynchronize(accs[i]->stream);
+    }
+    for (int i = 0; i < n; ++i) cdestroy(comms[i]);
+    if (e) return fail(QK_ERCCL, "ncclAllReduce: %s", errstr(e));
+  }
+  for (int i = 0; i < n; ++i) {
+    accs[i]->max_len = max_len;
+    accs[i]->n_reads = total_reads;
+  }
+  return QK_OK;
+}
+
+int qk_accum_finish(qk_accum *a, qk_base_info *out, uint64_t cap_positions,
+                    uint64_t *max_len, uint64_t *n_reads) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  int rc = qk_accum_sync(a);
+  if (rc) return rc;
+  if (max_len) *max_len = a->max_len;
+  if (n_reads) *n_reads = a->n_reads;
+  if (!out) return QK_OK;
+  if (cap_positions < a->max_len) return fail(QK_EINVAL, "output holds %llu positions, need %llu",
+                                               (unsigned long long)cap_positions, (unsigned long long)a->max_len);
+  if (a->max_len == 0) return QK_OK;
+  const uint64_t ml = a->max_len;
+  std::vector<uint64_t> planar((size_t)QK_N_ROWS * ml);
+  QK_HIP(hipMemcpy2D(planar.data(), ml * 8, a->d_table, a->table_len * 8, ml * 8, QK_N_ROWS,
+                     hipMemcpyDeviceToHost));
+  uint64_t *dst = reinterpret_cast<uint64_t *>(out);
+  for (uint64_t pos = 0; pos < ml; ++pos)
+    for (int row = 0; row < QK_N_ROWS; ++row)
+      dst[pos * QK_N_ROWS + row] = planar[(size_t)row * ml + pos];
+  return QK_OK;
+}
+
+int qk_accum_timing_enable(qk_accum *a, int on) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  a->timing = on != 0;
+  a->timing_ms = 0;
+  a->timing_launches = 0;
+  return QK_OK;
+}
+
+int qk_accum_timing_read(qk_accum *a, double *total_ms, uint64_t *launches) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  int rc = drain_timing(a);
+  if (rc) return rc;
+  if (total_ms) *total_ms = a->timing_ms;
+  if (launches) *launches = a->timing_launches;
+  return QK_OK;
+}
+
+}  // extern "C"
