@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the accumulation path (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (histogram kernel[s]) over one batch of
+synthetic reads that is already resident in HBM.  Workload at N=1 = the
+configuration the metric is quoted on: 10M-read synthetic 150 bp FASTQ, no
+adapters (BASELINE.json configs[1]); every rank holds its own 10M-read batch
+(weak scaling; the path shards by read batch with no data-path collective),
+and the job ends with the single RCCL all-reduce of the integer tables, which
+is inside the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel, algorithmic bytes (2 B/base [+8 B/read ragged])
+               / average launch duration from HIP events on the launch stream
+  cpu_baseline the oracle (CPU restatement, kind "port") on one host core over
+               the same batch — a reported baseline, not the target
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import quack_amd  # noqa: E402  (fails loudly when the native libraries are missing)
+from quack_amd import distributed as qd  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+WORKLOADS = {
+    # name: (reads, read_len, ragged (lo, hi), adapters, BASELINE.json config)
+    "cfg2": dict(n=10_000_000, L=150, ragged=None, adapters=False,
+                 label="10M-read synthetic 150 bp FASTQ, no adapters (BASELINE.json configs[1])"),
+    "cfg3": dict(n=10_000_000, L=300, ragged=None, adapters=True,
+                 label="10M-read synthetic 300 bp FASTQ + adapter FASTA (configs[2])"),
+    "cfg5": dict(n=143_000, L=20000, ragged=(1000, 20000), adapters=False,
+                 label="PacBio-style ragged 1-20 kb synthetic FASTQ (configs[4])"),
+}
+
+
+def make_batch(w, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    if w["ragged"]:
+        rng = np.random.default_rng(seed)
+        lens = rng.integers(w["ragged"][0], w["ragged"][1] + 1, w["n"])
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        total, max_len = int(off[-1]), int(lens.max())
+        d_off = torch.from_numpy(off).to(device)
+        q_lo, q_hi = 1, 60
+    else:
+        total, max_len, d_off = w["n"] * w["L"], w["L"], None
+        q_lo, q_hi = 2, 41
+    seq = torch.zeros(total + 16, dtype=torch.uint8, device=device)
+    qual = torch.zeros(total + 16, dtype=torch.uint8, device=device)
+    step = 1 << 28
+    for a in range(0, total, step):
+        b = min(total, a + step)
+        seq[a:b] = lut[torch.randint(0, 4, (b - a,), generator=g, device=device)]
+        qual[a:b] = (33 + torch.randint(q_lo, q_hi + 1, (b - a,), generator=g, device=device)).to(torch.uint8)
+    return seq, qual, d_off, total, max_len
+
+
+def synthetic_adapter_bits(seed=3):
+    """config 3's adapter FASTA: 24 records of 30-60 nt -> 2^20-bit table via
+    the product's read_adapters rule (quack_amd.host qkh_adapter_insert)"""
+    import ctypes
+    from quack_amd import _capi
+    rng = np.random.default_rng(seed)
+    bits = np.zeros(_capi.QK_KMER_TABLE_WORDS, dtype=np.uint32)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    ads = []
+    for _ in range(24):
+        s = acgt[rng.integers(0, 4, int(rng.integers(30, 61)))].copy()
+        ads.append(s)
+        _capi.host().qkh_adapter_insert(bits.ctypes.data, s.ctypes.data, len(s))
+    return bits, ads
+
+
+def cpu_baseline(seq, qual, d_off, n, total, w, ads):
+    """oracle on one host core over (a bounded sample of) the same batch"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    budget_bases = 3_000_000_000     # ~12 s at ~0.25 Gbases/s
+    kmers = ob.kmers_from_seqs([bytes(a) for a in ads]) if ads is not None else None
+    if d_off is None:
+        m = min(n, max(1, budget_bases // w["L"]))
+        hs, hq = seq[:m * w["L"]].cpu().numpy(), qual[:m * w["L"]].cpu().numpy()
+        t0 = time.perf_counter()
+        ob.accumulate_batch(hs, hq, read_len=w["L"], kmers=kmers)
+        dt = time.perf_counter() - t0
+        bases, sample = m * w["L"], "%d of %d reads x %d bp (same bytes as the GPU batch)" % (m, n, w["L"])
+    else:
+        off = d_off.cpu().numpy().astype(np.uint64)
+        m = int(min(n, np.searchsorted(off, budget_bases)))
+        hs, hq = seq[:int(off[m])].cpu().numpy(), qual[:int(off[m])].cpu().numpy()
+        t0 = time.perf_counter()
+        ob.accumulate_batch(hs, hq, off[:m + 1], kmers=kmers)
+        dt = time.perf_counter() - t0
+        bases, sample = int(off[m]), "%d of %d ragged reads (same bytes as the GPU batch)" % (m, n)
+    return {"value": bases / dt, "unit": "bases/s", "cores": 1, "kind": "port", "sample": sample,
+            "seconds": round(dt, 3), "host": "oracle/quack_oracle.c, single thread (quack is single-threaded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    w = WORKLOADS[args.workload]
+    bits, ads = synthetic_adapter_bits() if w["adapters"] else (None, None)
+    seq, qual, d_off, total, max_len = make_batch(w, seed=2 + rank, device=device)
+    n = w["n"]
+    alg_bytes = 2.0 * total + (8.0 * n if d_off is not None else 0.0)
+
+    acc = quack_amd.Accumulator(local, bits, max_len_hint=max_len)
+
+    def step():
+        acc.submit_device(seq, qual, d_off, n, total, max_len)
+
+    def fence():
+        acc.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    acc.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        qd.allreduce_accumulator(acc)       # the path's single exchange (RCCL over xGMI)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, launches = acc.timing_read()
+
+    # sanity: the counters must add up (every base carries one score and one content bin)
+    sd = acc.finish()
+    passes = (args.warmup + args.steps) * (world if world > 1 else 1)
+    expect = passes * total if world == 1 else None
+    got = int(sd.bases[:, 91:95].sum())
+    if world == 1 and got != expect:
+        raise SystemExit("counter check failed: content sum %d != %d" % (got, expect))
+
+    if rank == 0:
+        kernel_s = kernel_ms * 1e-3 / max(launches, 1)
+        achieved = alg_bytes / kernel_s / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(args.workload)
+        out = {
+            "metric": "bases/sec on synthetic 150 bp FASTQ; achieved HBM GB/s vs peak",
+            "value": world * args.steps * total / elapsed,
+            "unit": "bases/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": w["label"], "reads_per_gpu": n, "bases_per_gpu_per_step": total,
+                       "resident": "HBM", "parallelism": "batch-sharded x%d, one all-reduce of u64 tables" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "qk::hist_kernel", "kernel_ms": kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seq, qual, d_off, n, total, w, ads)
+        print(json.dumps(out), flush=True)
+    acc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,33 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE.  Produce the golden outputs under tests/golden/ by
+# running the REFERENCE ITSELF: its prebuilt binary
+#   /root/reference/bin/Linux_x86_64_kernel_3.10.0/quack   (quack 1.1.1, real klib)
+# quack.c cannot be compiled here (klib/kseq.h absent), so this binary is the
+# only executable form of the reference.  Only runs in the build container;
+# the outputs are committed (SVGs gzipped with -n for reproducible bytes).
+set -euo pipefail
+REF=${REF:-/root/reference/bin/Linux_x86_64_kernel_3.10.0/quack}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+G=$ROOT/tests/golden
+mkdir -p "$G/svg" "$G/cli"
+cd "$G/inputs"
+grep -v '^#' "$G/cases.tsv" | while IFS=$'\t' read -r name args; do
+  [ -z "$name" ] && continue
+  set +e
+  # shellcheck disable=SC2086
+  "$REF" $args > "$G/svg/$name.svg" 2> "$G/svg/$name.err"
+  rc=$?
+  set -e
+  echo "$rc" > "$G/svg/$name.rc"
+  gzip -n -9 -f "$G/svg/$name.svg"
+  echo "golden $name rc=$rc $(stat -c %s "$G/svg/$name.svg.gz") bytes"
+done
+grep -v '^#' "$G/cli_cases.tsv" | while IFS=$'\t' read -r name args; do
+  [ -z "$name" ] && continue
+  set +e
+  # shellcheck disable=SC2086
+  "$REF" $args > "$G/cli/$name.out" 2> "$G/cli/$name.err"
+  echo $? > "$G/cli/$name.rc"
+  set -e
+done
+echo "cli goldens: $(ls "$G/cli" | wc -l) files"

@@ -1,0 +1,67 @@
+"""One process per GPU: merging the per-rank counter tables.
+
+The accumulation shards by read batch with no data-path collective (every
+counter update is a commutative integer ++, quack.c:202,204,216,219,220).  At
+the end there is exactly one exchange: all-reduce(MAX) of the table length
+(1 word) and ONE all-reduce(SUM) of the integer tables — `ncclAllReduce` over
+xGMI when the process group is "nccl" (= RCCL on ROCm), gloo in the CPU tests.
+Integer sums are order-independent, so the result is bit-exact whatever
+algorithm the backend picks.
+"""
+import torch
+import torch.distributed as dist
+
+from ._capi import QK_N_ROWS
+
+
+def allreduce_planar(planar, table_len, group=None):
+    """planar: int64 tensor of QK_N_ROWS*table_len + 1 words (rows x positions,
+    then number_of_sequences).  Returns (summed tensor, common table_len)."""
+    if planar.dtype != torch.int64 or planar.numel() != QK_N_ROWS * table_len + 1:
+        raise ValueError("planar table must be int64[%d*table_len+1]" % QK_N_ROWS)
+    tl = torch.tensor([table_len], dtype=torch.int64, device=planar.device)
+    dist.all_reduce(tl, op=dist.ReduceOp.MAX, group=group)
+    common = int(tl.item())
+    if common != table_len:
+        wide = torch.zeros(QK_N_ROWS * common + 1, dtype=torch.int64, device=planar.device)
+        wide[:QK_N_ROWS * common].view(QK_N_ROWS, common)[:, :table_len] = \
+            planar[:QK_N_ROWS * table_len].view(QK_N_ROWS, table_len)
+        wide[-1] = planar[-1]
+        planar = wide
+    dist.all_reduce(planar, op=dist.ReduceOp.SUM, group=group)
+    return planar, common
+
+
+def allreduce_accumulator(acc, group=None):
+    """Sum this rank's qk_accum with every other rank's, in place (GPU path)."""
+    max_len, _ = acc.stats()
+    ml = torch.tensor([max_len], dtype=torch.int64, device="cuda:%d" % acc.device)
+    dist.all_reduce(ml, op=dist.ReduceOp.MAX, group=group)
+    # common geometry first, so that every rank exports the same number of words
+    words = torch.tensor([acc.table_words()], dtype=torch.int64, device=ml.device)
+    dist.all_reduce(words, op=dist.ReduceOp.MAX, group=group)
+    table_len = (int(words.item()) - 1) // QK_N_ROWS
+    acc.reserve(table_len)
+    assert acc.table_words() == QK_N_ROWS * table_len + 1
+    buf = torch.empty(acc.table_words(), dtype=torch.int64, device=ml.device)
+    acc.export_table(buf)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    acc.import_table(buf, int(ml.item()))
+    return acc
+
+
+def planar_from_bases(bases, number_of_sequences, table_len=None):
+    """[max_len, 97] reference layout -> planar int64 tensor (CPU helper)."""
+    import numpy as np
+    ml = bases.shape[0]
+    tl = table_len or max(ml, 1)
+    out = np.zeros(QK_N_ROWS * tl + 1, dtype=np.int64)
+    out[:QK_N_ROWS * tl].reshape(QK_N_ROWS, tl)[:, :ml] = bases.astype(np.int64).T
+    out[-1] = number_of_sequences
+    return torch.from_numpy(out), tl
+
+
+def bases_from_planar(planar, table_len, max_len):
+    import numpy as np
+    a = planar[:QK_N_ROWS * table_len].view(QK_N_ROWS, table_len)[:, :max_len].cpu().numpy()
+    return np.ascontiguousarray(a.T).astype(np.uint64), int(planar[-1].item())

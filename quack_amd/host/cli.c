@@ -1,0 +1,144 @@
+/*
+ * cli.c — quack's command line, restated (parse_options quack.c:59-132,
+ * main quack.c:858-928).  Same argv grammar, same stdout / stderr bytes, same
+ * exit codes.  Device selection is environment-only so the CLI stays a
+ * drop-in:  QUACK_DEVICES=0,1,...  (default: device 0).
+ *
+ * One deliberate difference: the reference prints the <svg> envelope before it
+ * reads the FASTQ and dies with SIGSEGV on an unreadable file (stdout empty,
+ * rc 139).  Here every input is accumulated first; on any failure a message
+ * goes to stderr, nothing to stdout, and the exit code is 1.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "quack_host.h"
+
+static const char *const k_version = "quack 1.1.1";   /* quack.c:54 */
+
+static const char *const k_help =                     /* quack.c:70-80 */
+    "Usage: quack [OPTION...]\n"
+    "quack -- A FASTQ quality assessment tool\n\n"
+    "  -1, --forward file.1.fq.gz      Forward strand\n"
+    "  -2, --reverse file.2.fq.gz      Reverse strand\n"
+    "  -a, --adapters adapters.fa.gz   (Optional) Adapters file\n"
+    "  -n, --name NAME                 (Optional) Display in output\n"
+    "  -u, --unpaired unpaired.fq.gz   Data (only use with -u)\n"
+    "  -?, --help                      Give this help list\n"
+    "      --usage                     (use alone)\n"
+    "  -V, --version                   Print program version (use alone)\n"
+    "Report bugs to <thrash@igbb.msstate.edu>.\n";
+
+static const char *const k_bad_option =               /* quack.c:113-123 */
+    "Usage: quack [OPTION...]\n"
+    "quack -- A FASTQ quality assessment tool\n\n"
+    "  -1, --forward file.1.fq.gz      Forward strand\n"
+    "  -2, --reverse file.2.fq.gz      Reverse strand\n"
+    "  -a, --adapters adapters.fa.gz    Adapters file\n"
+    "  -n, --name NAME            Display in output\n"
+    "  -u, --unpaired unpaired.fq.gz        Data (only use with -u)\n"
+    "  -?, --help                 Give this help list\n"
+    "      --usage                (use alone)\n"
+    "  -V, --version              Print program version (use alone)\n"
+    "Report bugs to <thrash@igbb.msstate.edu>.\n";
+
+static const char *const k_try_help =                 /* quack.c:873 */
+    "Usage: quack [OPTION...]\nTry `quack --help' or `quack --usage' for more information.";
+
+typedef struct {
+  const char *name, *forward, *reverse, *unpaired, *adapters;
+} options;
+
+static int is_opt(const char *arg, const char *s, const char *l) {
+  return strcmp(arg, s) == 0 || strcmp(arg, l) == 0;
+}
+
+static int parse_device_list(int *devs, int cap) {
+  const char *env = getenv("QUACK_DEVICES");
+  int n = 0;
+  if (!env || !*env) {
+    devs[0] = 0;
+    return 1;
+  }
+  while (*env && n < cap) {
+    char *end;
+    long v = strtol(env, &end, 10);
+    if (end == env) break;
+    devs[n++] = (int)v;
+    env = *end == ',' ? end + 1 : end;
+  }
+  if (n == 0) devs[n++] = 0;
+  return n;
+}
+
+int qkh_main(int argc, char **argv) {
+  options o = {0};
+  uint32_t *bitset = NULL;
+  qk_base_info *tab[2] = {NULL, NULL};
+  uint64_t max_len[2] = {0, 0}, n_reads[2] = {0, 0};
+  int devs[64], n_devs, paired, unpaired, rc = 1;
+
+  if (argc == 1 || argc == 2) {                       /* quack.c:68-87 */
+    if (argc == 1 || is_opt(argv[1], "-?", "--help") || strcmp(argv[1], "--usage") == 0)
+      fputs(k_help, stdout);
+    if (argc == 2 && is_opt(argv[1], "-V", "--version")) {
+      printf("%s\n", k_version);
+      return 0;
+    }
+  }
+  if (argc > 2 && argc % 2 != 0) {                    /* quack.c:89-130 */
+    for (int i = 1; i < argc; i += 2) {
+      const char *flag = argv[i], *val = argv[i + 1];
+      if (is_opt(flag, "-1", "--forward")) o.forward = val;
+      else if (is_opt(flag, "-2", "--reverse")) o.reverse = val;
+      else if (is_opt(flag, "-a", "--adapters")) o.adapters = val;
+      else if (is_opt(flag, "-u", "--unpaired")) o.unpaired = val;
+      else if (is_opt(flag, "-n", "--name")) o.name = val;
+      else {
+        fputs(k_bad_option, stderr);
+        return EXIT_FAILURE;
+      }
+    }
+  }
+  paired = o.forward != NULL && o.reverse != NULL;    /* quack.c:867-875 */
+  unpaired = o.unpaired != NULL;
+  if (paired == unpaired) {
+    printf("%s\n", k_try_help);
+    return 1;
+  }
+
+  if (o.adapters) {                                   /* quack.c:877 */
+    bitset = malloc(QK_KMER_TABLE_WORDS * sizeof(uint32_t));
+    if (!bitset || qkh_read_adapters(o.adapters, bitset)) {
+      fprintf(stderr, "quack: cannot read adapters file %s\n", o.adapters);
+      goto done;
+    }
+  }
+  n_devs = parse_device_list(devs, 64);
+
+  /* accumulate first (quack.c:911,917), print afterwards */
+  {
+    const char *files[2] = {paired ? o.forward : o.unpaired, paired ? o.reverse : NULL};
+    for (int k = 0; k < 2 && files[k]; k++) {
+      if (qkh_accumulate_file(files[k], bitset, devs, n_devs, &tab[k], &max_len[k], &n_reads[k])) {
+        fprintf(stderr, "quack: %s\n", qkh_last_error());
+        goto done;
+      }
+      if (max_len[k] == 0) {
+        fprintf(stderr, "quack: %s: no sequence data\n", files[k]);
+        goto done;
+      }
+    }
+  }
+  if (qkh_render_document(stdout, stderr, o.name, o.adapters != NULL, tab[0], max_len[0], n_reads[0],
+                          paired ? tab[1] : NULL, max_len[1], n_reads[1])) {
+    fprintf(stderr, "quack: nothing to draw\n");
+    goto done;
+  }
+  rc = 0;                                             /* quack.c:927 */
+done:
+  free(tab[0]);
+  free(tab[1]);
+  free(bitset);
+  return rc;
+}

@@ -1,0 +1,116 @@
+/*
+ * pipeline.c — whole-file accumulation: tokenizer -> pinned batches -> C-ABI.
+ *
+ * This is read_fastq() (quack.c:180-228) with its loop body moved to the GPU:
+ * the host thread parses records straight into the accumulator's pinned batch
+ * slot (qk_accum_acquire), commits it (async H2D + kernels on that slot's
+ * stream) and immediately parses the next batch into the other slot, so
+ * inflate/parse, PCIe copy and kernels overlap.  With several devices the
+ * batches are dealt round-robin and the integer tables are summed once with
+ * RCCL (qk_accum_allreduce).  There is no CPU fallback: any C-ABI error aborts
+ * the file.
+ */
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "quack_host.h"
+
+static _Thread_local char host_err[512];
+
+const char *qkh_last_error(void) { return host_err; }
+
+static int host_fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(host_err, sizeof host_err, fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+int qkh_accumulate_file(const char *path, const uint32_t *bitset,
+                        const int *devices, int n_devices,
+                        qk_base_info **bases_out, uint64_t *max_len,
+                        uint64_t *n_reads) {
+  qk_accum *accs[64];
+  qkh_reader *rd = NULL;
+  int rc = -1, turn = 0, made = 0;
+  *bases_out = NULL;
+  *max_len = *n_reads = 0;
+  if (n_devices < 1 || n_devices > 64) return host_fail("bad device count %d", n_devices);
+  for (; made < n_devices; made++)
+    if (qk_accum_create(&accs[made], devices[made], bitset, 0)) {
+      host_fail("device %d: %s", devices[made], qk_last_error());
+      goto out;
+    }
+  rd = qkh_reader_open(path);
+  if (!rd) {
+    host_fail("cannot open %s", path);
+    goto out;
+  }
+  while (!qkh_reader_done(rd)) {
+    uint8_t *seq, *qual;
+    uint64_t *offsets, cap_bytes, cap_reads, total = 0;
+    uint32_t uniform = 0;
+    int64_t n;
+    qk_accum *acc = accs[turn];
+    if (qk_accum_acquire(acc, &seq, &qual, &offsets, &cap_bytes, &cap_reads)) {
+      host_fail("%s", qk_last_error());
+      goto out;
+    }
+    n = qkh_reader_fill(rd, seq, qual, offsets, cap_bytes, cap_reads, &total, &uniform);
+    if (n < 0) {
+      host_fail(n == -4 ? "%s: a read exceeds the batch size (raise QUACK_HIP_BATCH_MB)"
+                        : "%s: out of memory while parsing", path);
+      goto out;
+    }
+    if (qk_accum_commit(acc, (uint64_t)n, total, uniform == 0, uniform)) {
+      host_fail("%s", qk_last_error());
+      goto out;
+    }
+    turn = (turn + 1) % n_devices;
+  }
+  if (n_devices > 1 && qk_accum_allreduce(accs, n_devices)) {
+    host_fail("%s", qk_last_error());
+    goto out;
+  }
+  if (qk_accum_finish(accs[0], NULL, 0, max_len, n_reads)) {
+    host_fail("%s", qk_last_error());
+    goto out;
+  }
+  if (*max_len) {
+    *bases_out = calloc(*max_len, sizeof(qk_base_info));
+    if (!*bases_out) {
+      host_fail("out of memory");
+      goto out;
+    }
+    if (qk_accum_finish(accs[0], *bases_out, *max_len, max_len, n_reads)) {
+      host_fail("%s", qk_last_error());
+      free(*bases_out);
+      *bases_out = NULL;
+      goto out;
+    }
+  }
+  rc = 0;
+out:
+  if (rd) qkh_reader_close(rd);
+  while (made-- > 0) qk_accum_destroy(accs[made]);
+  return rc;
+}
+
+int qkh_render_document(FILE *out, FILE *err, const char *name, int adapters,
+                        qk_base_info *fwd, uint64_t fwd_max_len, uint64_t fwd_reads,
+                        qk_base_info *rev, uint64_t rev_max_len, uint64_t rev_reads) {
+  qkh_svg w;
+  uint64_t original;
+  if (!fwd || fwd_max_len == 0 || (rev && rev_max_len == 0)) return -1;
+  qkh_svg_begin(&w, out, rev != NULL, adapters, name);
+  qkh_transform(fwd, &fwd_max_len, &original, fwd_reads, err);
+  qkh_draw(&w, fwd, fwd_max_len, fwd_reads, 0, adapters);
+  if (rev) {
+    qkh_transform(rev, &rev_max_len, &original, rev_reads, err);
+    qkh_draw(&w, rev, rev_max_len, rev_reads, 1, adapters);
+  }
+  qkh_svg_end(&w);
+  return 0;
+}

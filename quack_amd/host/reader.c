@@ -1,0 +1,288 @@
+/*
+ * reader.c — FASTQ/FASTA tokenizer + batcher feeding the accumulation path.
+ *
+ * Same record grammar as klib's kseq_read(), which quack instantiates over
+ * gzread (quack.c:152, 158-175, 182-222; klib is an absent submodule, so the
+ * grammar is implemented from its published behaviour and pinned by the
+ * reference binary's outputs in tests/):
+ *   - a record starts at the next '>' or '@'; name = up to first whitespace,
+ *     the rest of that line is ignored;
+ *   - sequence lines are concatenated until a line starts with '>', '@' or
+ *     '+'; empty lines are skipped; one trailing CR is dropped per line once
+ *     the accumulated text is longer than one byte;
+ *   - after '+', whole lines are appended to the quality until it is at least
+ *     as long as the sequence; a length mismatch or a missing quality ends the
+ *     stream (the reference's read loop stops at the first negative return,
+ *     quack.c:193).
+ * Unlike kseq, bytes go straight into the caller's batch arrays (the pinned
+ * staging buffers of the C-ABI): one memchr + one memcpy per line.  A record
+ * that does not fit in the rest of the batch is parked on the heap and opens
+ * the next batch.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include "quack_host.h"
+
+enum { QKH_IO_BUF = 4 << 20 };
+
+/* where the bytes of the record being parsed go */
+typedef struct {
+  uint8_t *dst;        /* current destination (batch memory or heap) */
+  size_t len, room;    /* bytes written / capacity of dst */
+  uint8_t **heap;      /* parking buffer (owned by the reader) */
+  size_t *heap_cap;
+  int parked;          /* 1: dst == *heap */
+} sink;
+
+struct qkh_reader {
+  gzFile f;
+  uint8_t *buf;
+  size_t pos, lim;
+  int eof;
+  int marker;          /* header marker already consumed ('>' / '@'), or 0 */
+  int finished;        /* no further records will be produced */
+  uint8_t *park_seq, *park_qual;
+  size_t park_seq_cap, park_qual_cap;
+  size_t park_len;
+  int have_parked, parked_is_fastq;
+};
+
+static int refill(qkh_reader *r) {
+  int n;
+  if (r->eof) return 0;
+  n = gzread(r->f, r->buf, QKH_IO_BUF);
+  r->pos = 0;
+  if (n <= 0) {
+    r->lim = 0;
+    r->eof = 1;
+    return 0;
+  }
+  r->lim = (size_t)n;
+  return 1;
+}
+
+static inline int next_byte(qkh_reader *r) {
+  if (r->pos >= r->lim && !refill(r)) return -1;
+  return r->buf[r->pos++];
+}
+
+/* move the record's bytes written so far to the reader-owned heap buffer */
+static int sink_park(sink *s, size_t need) {
+  size_t cap = *s->heap_cap ? *s->heap_cap : 4096;
+  while (cap < need) cap *= 2;
+  if (cap > *s->heap_cap || !*s->heap) {
+    uint8_t *h = realloc(*s->heap, cap);
+    if (!h) return -1;
+    *s->heap = h;
+    *s->heap_cap = cap;
+  }
+  if (!s->parked && s->len) memcpy(*s->heap, s->dst, s->len);
+  s->dst = *s->heap;
+  s->room = *s->heap_cap;
+  s->parked = 1;
+  return 0;
+}
+
+static int sink_put(sink *s, const uint8_t *p, size_t n) {
+  if (s->len + n > s->room && sink_park(s, s->len + n)) return -1;
+  if (n) memcpy(s->dst + s->len, p, n);
+  s->len += n;
+  return 0;
+}
+
+/* Consume through the next '\n'.  With a sink, the line's bytes are appended
+ * and the CR rule applied.  Returns 1 if any input was available, 0 if the
+ * stream was already exhausted, -1 on allocation failure. */
+static int take_line(qkh_reader *r, sink *s) {
+  int any = 0;
+  for (;;) {
+    const uint8_t *from, *nl;
+    size_t avail;
+    if (r->pos >= r->lim && !refill(r)) break;
+    any = 1;
+    from = r->buf + r->pos;
+    avail = r->lim - r->pos;
+    nl = memchr(from, '\n', avail);
+    if (nl) {
+      if (s && sink_put(s, from, (size_t)(nl - from))) return -1;
+      r->pos += (size_t)(nl - from) + 1;
+      break;
+    }
+    if (s && sink_put(s, from, avail)) return -1;
+    r->pos = r->lim;
+  }
+  if (any && s && s->len > 1 && s->dst[s->len - 1] == '\r') s->len--;
+  return any;
+}
+
+/* Skip the record name; returns the whitespace byte that ended it, 0 when the
+ * stream ended inside the name, -1 when there was nothing to read. */
+static int skip_name(qkh_reader *r) {
+  int any = 0;
+  for (;;) {
+    if (r->pos >= r->lim && !refill(r)) return any ? 0 : -1;
+    any = 1;
+    while (r->pos < r->lim) {
+      uint8_t c = r->buf[r->pos++];
+      if (c == ' ' || (c >= 9 && c <= 13)) return c;
+    }
+  }
+}
+
+/* One record.  Returns its length, -1 at end of stream, -2 for a malformed
+ * record, -3 when out of memory. */
+static long parse_record(qkh_reader *r, sink *sq, sink *ql, int *is_fastq) {
+  int c;
+  if (!r->marker) {
+    do c = next_byte(r); while (c >= 0 && c != '>' && c != '@');
+    if (c < 0) return -1;
+    r->marker = c;
+  }
+  c = skip_name(r);
+  if (c < 0) return -1;
+  if (c != '\n' && c != 0 && take_line(r, NULL) < 0) return -3;
+  for (;;) {
+    uint8_t first;
+    c = next_byte(r);
+    if (c < 0 || c == '>' || c == '+' || c == '@') break;
+    if (c == '\n') continue;
+    first = (uint8_t)c;
+    if (sink_put(sq, &first, 1) || take_line(r, sq) < 0) return -3;
+  }
+  r->marker = (c == '>' || c == '@') ? c : 0;
+  *is_fastq = c == '+';
+  if (c != '+') {
+    if (c >= 0) return (long)sq->len;
+    r->marker = 0;
+    return (long)sq->len;
+  }
+  do c = next_byte(r); while (c >= 0 && c != '\n');
+  if (c < 0) return -2;
+  for (;;) {
+    int got = take_line(r, ql);
+    if (got < 0) return -3;
+    if (got == 0 || ql->len >= sq->len) break;
+  }
+  r->marker = 0;
+  return ql->len == sq->len ? (long)sq->len : -2;
+}
+
+qkh_reader *qkh_reader_open(const char *path) {
+  qkh_reader *r = calloc(1, sizeof *r);
+  if (!r) return NULL;
+  r->buf = malloc(QKH_IO_BUF);
+  r->f = r->buf ? gzopen(path, "rb") : NULL;
+  if (!r->f) {
+    free(r->buf);
+    free(r);
+    return NULL;
+  }
+  gzbuffer(r->f, 1 << 20);
+  return r;
+}
+
+void qkh_reader_close(qkh_reader *r) {
+  if (!r) return;
+  gzclose(r->f);
+  free(r->buf);
+  free(r->park_seq);
+  free(r->park_qual);
+  free(r);
+}
+
+int qkh_reader_done(const qkh_reader *r) { return r->finished && !r->have_parked; }
+
+int64_t qkh_reader_fill(qkh_reader *r, uint8_t *seq, uint8_t *qual,
+                        uint64_t *offsets, uint64_t cap_bytes,
+                        uint64_t cap_reads, uint64_t *total_bytes,
+                        uint32_t *uniform_len) {
+  uint64_t n = 0, total = 0;
+  int64_t common = -1;   /* -1 unknown, -2 mixed */
+  offsets[0] = 0;
+  if (r->have_parked) {
+    if (r->park_len > cap_bytes) return -4;   /* a single read exceeds the batch */
+    memcpy(seq, r->park_seq, r->park_len);
+    if (r->parked_is_fastq) memcpy(qual, r->park_qual, r->park_len);
+    else memset(qual, 0, r->park_len);
+    total = r->park_len;
+    offsets[++n] = total;
+    common = (int64_t)r->park_len;
+    r->have_parked = 0;
+  }
+  while (!r->finished && n < cap_reads) {
+    sink sq = {seq + total, 0, cap_bytes - total, &r->park_seq, &r->park_seq_cap, 0};
+    sink ql = {qual + total, 0, cap_bytes - total, &r->park_qual, &r->park_qual_cap, 0};
+    int is_fastq = 0;
+    long l = parse_record(r, &sq, &ql, &is_fastq);
+    if (l == -3) return -3;
+    if (l < 0) {
+      r->finished = 1;
+      break;
+    }
+    if (sq.parked || ql.parked) {
+      /* did not fit: keep the whole record on the heap for the next batch */
+      if (!sq.parked && sink_park(&sq, sq.len + 1)) return -3;
+      if (!ql.parked && sink_park(&ql, ql.len + 1)) return -3;
+      r->park_len = (size_t)l;
+      r->have_parked = 1;
+      r->parked_is_fastq = is_fastq;
+      if (n == 0 && (uint64_t)l > cap_bytes) return -4;
+      break;
+    }
+    if (!is_fastq) memset(qual + total, 0, (size_t)l);  /* FASTA fed as reads: no scores */
+    total += (uint64_t)l;
+    offsets[++n] = total;
+    if (common == -1) common = l;
+    else if (common != l) common = -2;
+  }
+  *total_bytes = total;
+  *uniform_len = (common > 0 && common <= 0x7FFFFFFF) ? (uint32_t)common : 0;
+  return (int64_t)n;
+}
+
+/* ----------------------------------------------------------------- adapters */
+
+static inline uint32_t letter_code(uint8_t c) {
+  /* quack.c:148-150: A C G T at lookup[0], [2], [6], [19]; (c-65)&~32 == key-1
+   * for letters, and key = c & 31 */
+  switch (c & 31u) {
+    case 20: return 1;
+    case 3: return 2;
+    case 7: return 3;
+    default: return 0;
+  }
+}
+
+void qkh_adapter_insert(uint32_t *bitset, const uint8_t *seq, uint64_t len) {
+  uint32_t idx = 0;
+  uint64_t i;
+  if (len <= QK_KMER_SIZE) return;
+  for (i = 0; i < QK_KMER_SIZE; i++)                 /* quack.c:166-168 */
+    idx = ((idx << 2) + letter_code(seq[i])) & (QK_KMER_TABLE_BITS - 1);
+  for (; i < len; i++) {                             /* quack.c:169-172 */
+    idx = ((idx << 2) + letter_code(seq[i])) & (QK_KMER_TABLE_BITS - 1);
+    bitset[idx >> 5] |= 1u << (idx & 31);
+  }
+}
+
+int qkh_read_adapters(const char *path, uint32_t *bitset) {
+  qkh_reader *r = qkh_reader_open(path);
+  uint8_t *s = NULL, *q = NULL;
+  size_t scap = 0, qcap = 0;
+  if (!r) return -1;
+  memset(bitset, 0, QK_KMER_TABLE_WORDS * sizeof(uint32_t));
+  for (;;) {
+    sink sq = {NULL, 0, 0, &s, &scap, 0};
+    sink ql = {NULL, 0, 0, &q, &qcap, 0};
+    int is_fastq;
+    long l = parse_record(r, &sq, &ql, &is_fastq);
+    if (l < 0) break;                                /* quack.c:164 */
+    qkh_adapter_insert(bitset, sq.dst, (uint64_t)l);
+  }
+  free(s);
+  free(q);
+  qkh_reader_close(r);
+  return 0;
+}

@@ -1,0 +1,47 @@
+"""Golden case manifest (tests/golden/cases.tsv) shared by several tests."""
+import gzip
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+FLAGS = {"-u": "u", "--unpaired": "u", "-1": "1", "--forward": "1", "-2": "2", "--reverse": "2",
+         "-a": "a", "--adapters": "a", "-n": "n", "--name": "n"}
+
+
+def load(manifest="cases.tsv"):
+    out = []
+    for line in open(os.path.join(G, manifest)):
+        if line.startswith("#") or not line.strip():
+            continue
+        name, _, args = line.rstrip("\n").partition("\t")
+        out.append((name, args.split()))
+    return out
+
+
+def options(argv):
+    opt = {}
+    for i in range(0, len(argv) - 1, 2):
+        opt[FLAGS[argv[i]]] = argv[i + 1]
+    return opt
+
+
+def golden_svg(name):
+    with gzip.open(os.path.join(G, "svg", name + ".svg.gz")) as f:
+        return f.read()
+
+
+def golden_err(name):
+    with open(os.path.join(G, "svg", name + ".err"), "rb") as f:
+        return f.read()
+
+
+def inp(name):
+    return os.path.join(G, "inputs", name)
+
+
+# fixtures with 100 equal-length reads and only valid qualities: every raw
+# counter is readable from the reference's SVG
+EXACT_100 = {"uniform100", "uniform100_gz", "uniform100_named", "uniform100_adapters",
+             "uniform100_longflags", "adapter100", "adapter100_noadapters", "crlf100", "multiline100",
+             "truncated100", "nonewline100", "phred64_100", "unpaired_wins_over_half_pair"}
+BINNED = {"long40", "long40_adapters"}

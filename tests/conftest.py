@@ -1,0 +1,45 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _build_if_missing():
+    need_oracle = not os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
+    need_native = not (os.path.exists(os.path.join(ROOT, "quack_amd", "libquack_hip.so"))
+                       and os.path.exists(os.path.join(ROOT, "quack_amd", "libquack_host.so"))
+                       and os.path.exists(os.path.join(ROOT, "quack_amd", "host", "quack")))
+    if need_oracle:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    if need_native:
+        subprocess.check_call(["make", "-C", ROOT, "all"])
+
+
+_build_if_missing()
+
+
+@pytest.fixture(scope="session")
+def root():
+    return ROOT
+
+
+@pytest.fixture(scope="session")
+def inputs():
+    return os.path.join(ROOT, "tests", "golden", "inputs")
+
+
+def has_gpu():
+    try:
+        import quack_amd
+        return quack_amd.device_count() > 0
+    except Exception:
+        return False

@@ -1,0 +1,119 @@
+"""BASELINE.json configurations at full size on one MI355X, device-resident
+(generated on the GPU), checked through size-independent properties and — the
+oracle manages ~0.25 Gbases/s on one core — exactly against the oracle for
+config 2 and config 5."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import synth
+import quack_amd
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def device_fixed(n, L, seed, q_lo=2, q_hi=41):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    seq = torch.zeros(n * L + 16, dtype=torch.uint8, device="cuda")
+    qual = torch.zeros(n * L + 16, dtype=torch.uint8, device="cuda")
+    step = 1 << 28
+    for a in range(0, n * L, step):
+        b = min(n * L, a + step)
+        seq[a:b] = lut[torch.randint(0, 4, (b - a,), generator=g, device="cuda")]
+        qual[a:b] = (33 + torch.randint(q_lo, q_hi + 1, (b - a,), generator=g, device="cuda")).to(torch.uint8)
+    return seq, qual
+
+
+def run_device(seq, qual, off, n, total, max_len, bits=None, passes=1):
+    with quack_amd.Accumulator(0, bits) as acc:
+        for _ in range(passes):
+            acc.submit_device(seq, qual, off, n, total, max_len)
+        return acc.finish()
+
+
+def test_config2_10M_x_150_exact_and_properties():
+    n, L = 10_000_000, 150
+    seq, qual = device_fixed(n, L, seed=2)
+    sd = run_device(seq, qual, None, n, n * L, L)
+    b = sd.bases.astype(np.int64)
+    assert sd.number_of_sequences == n and sd.max_length == L
+    assert (b[:, :91].sum(axis=1) == n).all()          # every base has one valid score
+    assert (b[:, 91:95].sum(axis=1) == n).all()        # ... and one content bin
+    assert b[:, 95].sum() == n and b[L - 1, 95] == n   # one length per read
+    assert b[10, 96] == n and b[:, 96].sum() == n      # kmers == NULL: bases[10].kmer_count++ (quack.c:215)
+    assert b[:, :2].sum() == 0 and b[:, 42:91].sum() == 0   # Q in [2,41] only
+    # idempotence/linearity: a second pass doubles every counter
+    sd2 = run_device(seq, qual, None, n, n * L, L, passes=2)
+    np.testing.assert_array_equal(sd2.bases, 2 * sd.bases)
+    # exact, against the oracle on the same bytes
+    want, wn = ob.accumulate_batch(seq[:n * L].cpu().numpy(), qual[:n * L].cpu().numpy(), read_len=L)
+    assert wn == n
+    np.testing.assert_array_equal(sd.bases, want)
+
+
+def test_config3_10M_x_300_adapters_properties_and_sampled_exact():
+    n, L = 10_000_000, 300
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    bits = ob.kmers_to_bitset(k)
+    seq, qual = device_fixed(n, L, seed=3)
+    # splice adapters into 25 % of the reads of the first 2M on the host, upload
+    m = 2_000_000
+    head = synth.splice_adapters(seq[:m * L].cpu().numpy(), L, ads, seed=33)
+    seq[:m * L] = torch.from_numpy(head).cuda()
+    sd = run_device(seq, qual, None, n, n * L, L, bits)
+    b = sd.bases.astype(np.int64)
+    assert sd.number_of_sequences == n and sd.max_length == L
+    assert (b[:, :91].sum(axis=1) == n).all() and (b[:, 91:95].sum(axis=1) == n).all()
+    assert b[L - 1, 95] == n
+    assert 0 < b[:, 96].sum() <= n and b[:10, 96].sum() == 0     # at most one first hit per read, never before 10
+    # the first 2M reads exactly; the remainder through additivity
+    head_t = run_device(seq, qual, None, m, m * L, L, bits)
+    want, _ = ob.accumulate_batch(head, qual[:m * L].cpu().numpy(), read_len=L, kmers=k)
+    np.testing.assert_array_equal(head_t.bases, want)
+    tail_t = run_device(seq[m * L:], qual[m * L:], None, n - m, (n - m) * L, L, bits)
+    np.testing.assert_array_equal(head_t.bases + tail_t.bases, sd.bases)
+
+
+def test_config5_ragged_1kb_to_20kb_exact():
+    rng = np.random.default_rng(6)
+    n = 143_000
+    lens = rng.integers(1000, 20001, n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(off[-1])
+    g = torch.Generator(device="cuda").manual_seed(6)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    seq = torch.zeros(total + 16, dtype=torch.uint8, device="cuda")
+    qual = torch.zeros(total + 16, dtype=torch.uint8, device="cuda")
+    seq[:total] = lut[torch.randint(0, 4, (total,), generator=g, device="cuda")]
+    qual[:total] = (33 + torch.randint(1, 61, (total,), generator=g, device="cuda")).to(torch.uint8)
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    sd = run_device(seq, qual, d_off, n, total, int(lens.max()))
+    assert sd.number_of_sequences == n and sd.max_length == int(lens.max())
+    b = sd.bases.astype(np.int64)
+    cover = n - np.searchsorted(np.sort(lens), np.arange(sd.max_length), side="right")   # reads longer than pos
+    assert (b[:, :91].sum(axis=1) == cover).all() and (b[:, 91:95].sum(axis=1) == cover).all()
+    assert (b[:, 95] == np.bincount(lens - 1, minlength=sd.max_length)).all()
+    want, _ = ob.accumulate_batch(seq[:total].cpu().numpy(), qual[:total].cpu().numpy(), off)
+    np.testing.assert_array_equal(sd.bases, want)
+
+
+def test_config4_shape_two_independent_accumulators():
+    """paired = two independent accumulations (quack.c:911-921); sharding the
+    batches of each mate over accumulators and summing equals one pass"""
+    n, L = 2_000_000, 150
+    f_seq, f_qual = device_fixed(n, L, seed=4)
+    r_seq, r_qual = device_fixed(n, L, seed=5, q_hi=30)
+    whole = [run_device(s, q, None, n, n * L, L) for s, q in ((f_seq, f_qual), (r_seq, r_qual))]
+    assert not np.array_equal(whole[0].bases, whole[1].bases)
+    shards = 8
+    per = n // shards
+    for (s, q), w in zip(((f_seq, f_qual), (r_seq, r_qual)), whole):
+        acc = np.zeros_like(w.bases)
+        for k in range(shards):                      # what 8 ranks would each compute
+            a = k * per * L
+            part = run_device(s[a:], q[a:], None, per, per * L, L)
+            acc += part.bases
+        np.testing.assert_array_equal(acc, w.bases)  # what the all-reduce(SUM) yields

@@ -1,0 +1,225 @@
+"""Parity of the HIP path (through the C-ABI) with the oracle.  Needs an
+MI355X: run with `pytest -m gpu`.  Integer work: the bar is bit-exact."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_binding as ob
+import synth
+import quack_amd
+from quack_amd.api import pad_for_device
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_table(seq, qual, offsets=None, read_len=0, kmers_bits=None, chunks=1, **cfg):
+    with quack_amd.Accumulator(0, kmers_bits) as acc:
+        if cfg:
+            acc.configure(**cfg)
+        if offsets is None:
+            n = len(seq) // read_len
+            cut = [n * i // chunks for i in range(chunks + 1)]
+            for a, b in zip(cut, cut[1:]):
+                acc.submit_fixed(seq[a * read_len:b * read_len], qual[a * read_len:b * read_len], read_len)
+        else:
+            n = len(offsets) - 1
+            cut = [n * i // chunks for i in range(chunks + 1)]
+            for a, b in zip(cut, cut[1:]):
+                lo, hi = int(offsets[a]), int(offsets[b])
+                acc.submit(seq[lo:hi], qual[lo:hi], offsets[a:b + 1] - offsets[a])
+        sd = acc.finish()
+    return sd.bases, sd.number_of_sequences
+
+
+def assert_same(got, want):
+    gb, gn = got
+    wb, wn = want
+    assert gn == wn
+    assert gb.shape == wb.shape
+    if not np.array_equal(gb, wb):
+        pos, row = np.argwhere(gb != wb)[0]
+        raise AssertionError("first mismatch at position %d row %d: hip %d oracle %d (%d cells differ)"
+                             % (pos, row, gb[pos, row], wb[pos, row], (gb != wb).sum()))
+
+
+# ---------------------------------------------------------------- seeded batches
+@pytest.mark.parametrize("n,L", [(20000, 150), (5000, 300), (70000, 36), (3000, 8), (3000, 9),
+                                 (1, 150), (1000, 1), (999, 151), (2000, 250), (300, 1000)])
+def test_fixed_length(n, L):
+    seq, qual = synth.fixed(n, L, seed=n + L)
+    assert_same(hip_table(seq, qual, read_len=L), ob.accumulate_batch(seq, qual, read_len=L))
+
+
+@pytest.mark.parametrize("n,lo,hi", [(30000, 1, 150), (20000, 20, 151), (50000, 1, 12), (400, 1000, 20000),
+                                     (64, 5000, 5000), (5000, 0, 40)])
+def test_ragged(n, lo, hi):
+    seq, qual, off = synth.ragged(n, lo, hi, seed=n + hi, q_lo=1, q_hi=60, alphabet=b"ACGTNacgtnRYKM")
+    assert_same(hip_table(seq, qual, off), ob.accumulate_batch(seq, qual, off))
+
+
+@pytest.mark.parametrize("L", [300, 150, 40])
+def test_adapters_fixed(L):
+    ads = synth.synthetic_adapters()
+    seq, qual = synth.fixed(20000, L, seed=3)
+    seq = synth.splice_adapters(seq, L, ads, seed=4)
+    k = ob.kmers_from_seqs(ads)
+    assert_same(hip_table(seq, qual, read_len=L, kmers_bits=ob.kmers_to_bitset(k)),
+                ob.accumulate_batch(seq, qual, read_len=L, kmers=k))
+    assert ob.accumulate_batch(seq, qual, read_len=L, kmers=k)[0][:, 96].sum() > 100  # hits happened
+
+
+def test_adapters_ragged_and_long():
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    for n, lo, hi in [(20000, 1, 120), (300, 1000, 20000)]:
+        seq, qual, off = synth.ragged(n, lo, hi, seed=hi)
+        rng = np.random.default_rng(5)
+        for r in rng.integers(0, n, n // 3):           # splice adapters anywhere, also near the end
+            a, b = int(off[r]), int(off[r + 1])
+            ad = np.frombuffer(ads[int(rng.integers(0, len(ads)))], np.uint8)
+            at = a + int(rng.integers(0, max(1, b - a)))
+            m = min(len(ad), b - at)
+            seq[at:at + m] = ad[:m]
+        assert_same(hip_table(seq, qual, off, kmers_bits=ob.kmers_to_bitset(k)),
+                    ob.accumulate_batch(seq, qual, off, kmers=k))
+
+
+def test_adapter_hit_positions_edge_cases():
+    """first window un-inserted, hit in the seed window, hit ending on the last
+    base (not counted), l == 10, l < 10 — SURVEY §8a rows a6/a7"""
+    k = ob.kmers_from_seqs(["ACGTTGCAAGGCT"])
+    reads = [b"ACGTTGCAAGAAAA", b"CGTTGCAAGGAA", b"AACGTTGCAAGGAA", b"AACGTTGCAAGG", b"CGTTGCAAGG", b"NGT",
+             b"CGTTGCAAGGCTAAAAAAAAAAAAAAAAAAAACGTTGCAAGG"]
+    seq = np.frombuffer(b"".join(reads), np.uint8)
+    qual = np.full(len(seq), ord("5"), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    got = hip_table(seq, qual, off, kmers_bits=ob.kmers_to_bitset(k))
+    assert_same(got, ob.accumulate_batch(seq, qual, off, kmers=k))
+    assert got[0][10, 96] == 2 and got[0][12, 96] == 1
+
+
+def test_every_byte_value_is_defined_and_identical():
+    """bytes outside the reference's defined domain (UB there) follow the rules
+    fixed in oracle/quack_oracle.c — identically on the GPU"""
+    rng = np.random.default_rng(11)
+    lens = rng.integers(1, 200, 20000)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    seq = rng.integers(0, 256, int(off[-1])).astype(np.uint8)
+    qual = rng.integers(0, 256, int(off[-1])).astype(np.uint8)
+    k = ob.kmers_from_seqs(synth.synthetic_adapters())
+    assert_same(hip_table(seq, qual, off), ob.accumulate_batch(seq, qual, off))
+    assert_same(hip_table(seq, qual, off, kmers_bits=ob.kmers_to_bitset(k)),
+                ob.accumulate_batch(seq, qual, off, kmers=k))
+
+
+def test_four_level_quality_worst_case_contention():
+    rng = np.random.default_rng(9)
+    n, L = 40000, 150
+    seq, _ = synth.fixed(n, L, seed=9)
+    qual = (33 + np.array([2, 12, 23, 37], np.uint8)[rng.choice(4, n * L, p=[.03, .05, .12, .80])]).astype(np.uint8)
+    assert_same(hip_table(seq, qual, read_len=L), ob.accumulate_batch(seq, qual, read_len=L))
+
+
+# ------------------------------------------------------- accumulation mechanics
+def test_many_submits_and_table_growth():
+    """short reads first, longer later (realloc path, quack.c:194-198);
+    fixed and ragged batches mixed into one accumulator"""
+    parts = [synth.ragged(5000, 1, 30, seed=1), synth.ragged(5000, 10, 140, seed=2),
+             synth.ragged(500, 200, 3000, seed=3)]
+    f_seq, f_qual = synth.fixed(4000, 100, seed=4)
+    with quack_amd.Accumulator(0, None, max_len_hint=16) as acc:
+        for s, q, o in parts:
+            acc.submit(s, q, o)
+        acc.submit_fixed(f_seq, f_qual, 100)
+        sd = acc.finish()
+    seq = np.concatenate([p[0] for p in parts] + [f_seq])
+    qual = np.concatenate([p[1] for p in parts] + [f_qual])
+    lens = np.concatenate([np.diff(p[2].astype(np.int64)) for p in parts] + [np.full(4000, 100)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    assert_same((sd.bases, sd.number_of_sequences), ob.accumulate_batch(seq, qual, off))
+
+
+def test_pinned_pipeline_many_small_batches(monkeypatch):
+    monkeypatch.setenv("QUACK_HIP_BATCH_MB", "1")
+    seq, qual, off = synth.ragged(60000, 50, 150, seed=21)       # ~6 MB -> >= 6 slot turnovers
+    assert_same(hip_table(seq, qual, off), ob.accumulate_batch(seq, qual, off))
+    seq, qual = synth.fixed(50000, 150, seed=22)
+    assert_same(hip_table(seq, qual, read_len=150), ob.accumulate_batch(seq, qual, read_len=150))
+
+
+@pytest.mark.parametrize("cfg", [dict(threads=512, unroll=2, tile=96, wgs_per_cu=4),
+                                 dict(threads=256, unroll=4, tile=64, wgs_per_cu=8),
+                                 dict(threads=1024, unroll=1, tile=304, wgs_per_cu=1),
+                                 dict(threads=1024, unroll=4, tile=8, wgs_per_cu=2)])
+def test_launch_configurations_are_equivalent(cfg):
+    seq, qual, off = synth.ragged(20000, 1, 320, seed=31)
+    assert_same(hip_table(seq, qual, off, **cfg), ob.accumulate_batch(seq, qual, off))
+    seq, qual = synth.fixed(20000, 150, seed=32)
+    assert_same(hip_table(seq, qual, read_len=150, **cfg), ob.accumulate_batch(seq, qual, read_len=150))
+
+
+def test_empty_inputs():
+    with quack_amd.Accumulator(0) as acc:
+        acc.submit(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+        sd = acc.finish()
+    assert sd.max_length == 0 and sd.number_of_sequences == 0
+    # zero-length reads count as sequences only (quack.c:219 is undefined there)
+    seq, qual, off = synth.ragged(100, 0, 0, seed=1)
+    got = hip_table(seq, qual, off)
+    assert got[1] == 100 and got[0].shape[0] == 0
+
+
+def test_linearity_and_determinism():
+    seq, qual, off = synth.ragged(40000, 1, 200, seed=41)
+    whole = hip_table(seq, qual, off)
+    again = hip_table(seq, qual, off)
+    split = hip_table(seq, qual, off, chunks=7)
+    assert_same(again, whole)
+    assert_same(split, whole)
+
+
+# ------------------------------------------------------------ reference goldens
+QUACK = os.path.join(cases.ROOT, "quack_amd", "host", "quack")
+
+
+@pytest.mark.parametrize("name,argv", cases.load(), ids=[c[0] for c in cases.load()])
+def test_cli_is_a_drop_in(name, argv):
+    """the C CLI on the GPU writes the reference binary's bytes"""
+    r = subprocess.run([QUACK] + argv, capture_output=True, cwd=cases.inp(""))
+    assert r.returncode == 0, r.stderr
+    assert r.stderr == cases.golden_err(name)
+    assert r.stdout == cases.golden_svg(name)
+
+
+@pytest.mark.parametrize("fname,adapters", [("uniform100.fq.gz", None), ("adapter100.fq", "adapters.fa"),
+                                            ("ragged100_2member.fq.gz", "adapters.fa.gz"),
+                                            ("long40.fq.gz", "adapters.fa"), ("multiline100.fq", None),
+                                            ("one_base.fq", None), ("kat.fq", "kat_adapter.fa")])
+def test_read_fastq_mirror(fname, adapters):
+    bits = quack_amd.read_adapters(cases.inp(adapters)) if adapters else None
+    k = ob.kmers_from_file(cases.inp(adapters)) if adapters else None
+    sd = quack_amd.read_fastq(cases.inp(fname), bits)
+    assert_same((sd.bases, sd.number_of_sequences), ob.read_fastq(cases.inp(fname), k))
+
+
+def test_device_table_roundtrip_and_single_rank_allreduce():
+    """export -> all-reduce (world of one, RCCL) -> import leaves the table intact"""
+    import torch
+    import torch.distributed as dist
+    from quack_amd import distributed as qd
+    seq, qual, off = synth.ragged(20000, 1, 150, seed=51)
+    want = ob.accumulate_batch(seq, qual, off)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        with quack_amd.Accumulator(0) as acc:
+            acc.submit(seq, qual, off)
+            qd.allreduce_accumulator(acc)
+            sd = acc.finish()
+        assert_same((sd.bases, sd.number_of_sequences), want)
+    finally:
+        dist.destroy_process_group()
