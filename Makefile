@@ -26,11 +26,13 @@ host:
 oracle:
 	$(MAKE) -C oracle
 
-tools: tools/kbench
+tools: tools/kbench tools/gen_fastq
+tools/gen_fastq: tools/gen_fastq.c
+	$(CC) -O2 -o $@ $< -lz
 tools/kbench: tools/kbench.cpp $(CSRC)/qk_shim.hip $(KERNEL_HDRS) include/quack_hip.h
 	$(HIPCC) $(HIPFLAGS) -DQK_ABLATION -o $@ tools/kbench.cpp $(CSRC)/qk_shim.hip -ldl
 
 clean:
-	rm -f $(LIB_HIP) tools/kbench
+	rm -f $(LIB_HIP) tools/kbench tools/gen_fastq
 	-$(MAKE) -C $(HOST) clean
 	-$(MAKE) -C oracle clean

@@ -31,3 +31,16 @@ grep -v '^#' "$G/cli_cases.tsv" | while IFS=$'\t' read -r name args; do
   set -e
 done
 echo "cli goldens: $(ls "$G/cli" | wc -l) files"
+
+# BASELINE.json configs[0]: `quack -u` on 100k-read synthetic 150 bp gzipped
+# FASTQ.  The 16.8 MB input is not committed; tools/gen_fastq regenerates it
+# bit-identically (splitmix64, seed 12345) wherever the test runs.
+if [ -x "$ROOT/tools/gen_fastq" ]; then
+  TMP=$(mktemp -d)
+  "$ROOT/tools/gen_fastq" "$TMP/config1.fq.gz" 100000 150 150 12345
+  (cd "$TMP" && "$REF" -u config1.fq.gz > "$G/svg/config1.svg" 2> "$G/svg/config1.err"; echo $? > "$G/svg/config1.rc")
+  sha256sum "$TMP/config1.fq.gz" | cut -d' ' -f1 > "$G/svg/config1.input.sha256"
+  gzip -n -9 -f "$G/svg/config1.svg"
+  echo "golden config1 $(stat -c %s "$G/svg/config1.svg.gz") bytes"
+  rm -rf "$TMP"
+fi

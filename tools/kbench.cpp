@@ -55,6 +55,7 @@ int main(int argc, char **argv) {
   int only_cfg = argc > 5 ? atoi(argv[5]) : -1;   // -1: sweep all
   int only_mode = argc > 6 ? atoi(argv[6]) : -1;
   int skip_check = argc > 7 ? atoi(argv[7]) : 0;
+  int h2d = argc > 8 ? atoi(argv[8]) : 0;   // 1: also time the pinned H2D pipeline
 
   // ---- synthetic batch -------------------------------------------------
   std::vector<uint64_t> off(n_reads + 1);
@@ -191,5 +192,36 @@ int main(int argc, char **argv) {
     }
   }
   qk_debug_set_mode(0);
+
+  // ---- H2D-inclusive: pinned double-buffered slots, hipMemcpyAsync + kernels
+  if (h2d && !ragged) {
+    qk_accum *acc;
+    CK(qk_accum_create(&acc, 0, adapters ? bits.data() : nullptr, max_len));
+    uint8_t *hs, *hq;
+    uint64_t *ho, capb, capr;
+    const int rounds = 40;
+    uint64_t per = 0;
+    for (int i = 0; i < rounds + 2; ++i) {
+      CK(qk_accum_acquire(acc, &hs, &hq, &ho, &capb, &capr));
+      per = capb / read_len;
+      if (i < 2) {  // fill each slot once with real reads (afterwards the bytes stay)
+        memcpy(hs, seq.data(), per * read_len);
+        memcpy(hq, qual.data(), per * read_len);
+      }
+      CK(qk_accum_commit(acc, per, per * read_len, 0, read_len));
+      if (i == 1) CK(qk_accum_sync(acc));
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < rounds; ++i) {
+      CK(qk_accum_acquire(acc, &hs, &hq, &ho, &capb, &capr));
+      CK(qk_accum_commit(acc, per, per * read_len, 0, read_len));
+    }
+    CK(qk_accum_sync(acc));
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    double bases = (double)rounds * per * read_len;
+    printf("h2d pipeline: %d batches x %llu reads (%.0f MiB/array): %.2f Gbases/s, %.1f GB/s over PCIe\n", rounds,
+           (unsigned long long)per, per * read_len / 1048576.0, bases / dt / 1e9, 2 * bases / dt / 1e9);
+    qk_accum_destroy(acc);
+  }
   return 0;
 }

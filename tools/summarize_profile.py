@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the small files
+committed under profiles/:  <tag>_kernel_stats.csv, <tag>_pmc.json,
+<tag>_summary.md, and the per-workload entry of profiles/hbm_traffic.json that
+bench.py reports as roofline.traffic.
+
+HBM traffic per launch = 2 * FETCH_SIZE + WRITE_SIZE   (KB -> bytes)
+  - FETCH_SIZE / WRITE_SIZE come from separate --pmc passes (TCC slots);
+  - gfx950 tallies the 128-B requests of a coalesced stream at 64 B, so
+    FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section);
+  - the guide calibrates that factor for 16 B/lane loads only; this kernel
+    loads 8 B/lane, so the factor is checked against a loads-only build of the
+    same kernel that reads every byte exactly once (pmc_calib).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(d, kern):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kern in r["Kernel_Name"]:
+                out[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+
+def main():
+    tag, workload, alg_bytes = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    kern = sys.argv[4] if len(sys.argv) > 4 else "hist_kernel"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    rows = []
+    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            name = r["Name"]
+            r["Name"] = name if len(name) < 100 else name[:60] + "...<%d chars>" % len(name)
+            rows.append(r)
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    k = [r for r in rows if kern in r["Name"]][0]
+    pmc, cnt = {}, {}
+    for sub in ("pmc_fetch", "pmc_write", "pmc_tcc", "pmc_tcc2"):
+        a, b = counters(os.path.join(src, sub), kern)
+        pmc.update(a)
+        cnt.update(b)
+    calib, _ = counters(os.path.join(src, "pmc_calib"), kern)
+    fetch_b = pmc.get("FETCH_SIZE", 0) * 1024
+    write_b = pmc.get("WRITE_SIZE", 0) * 1024
+    traffic = 2 * fetch_b + write_b
+    info = {"tag": tag, "workload": workload, "kernel": k["Name"], "calls": int(k["Calls"]),
+            "avg_ns": float(k["AverageNs"]), "min_ns": float(k["MinNs"]), "max_ns": float(k["MaxNs"]),
+            "algorithmic_bytes_per_launch": alg_bytes, "pmc_per_launch": pmc, "pmc_samples": cnt,
+            "hbm_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / alg_bytes,
+            "achieved_GBs_from_trace": alg_bytes / float(k["AverageNs"])}
+    if calib:
+        info["calibration_loads_only_FETCH_SIZE_KB"] = calib.get("FETCH_SIZE")
+        info["calibration_factor_for_8B_per_lane"] = alg_bytes / (calib["FETCH_SIZE"] * 1024)
+    json.dump(info, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
+    tf = os.path.join(dst, "hbm_traffic.json")
+    t = json.load(open(tf)) if os.path.exists(tf) else {}
+    t[workload] = traffic
+    json.dump(t, open(tf, "w"), indent=1)
+    with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
+        f.write("# rocprofv3 summary %s (%s)\n\n" % (tag, workload))
+        f.write("Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline%s`\n\n"
+                % ("" if workload == "cfg2" else " --workload " + workload))
+        f.write("| kernel | calls | avg µs | min µs | max µs | algorithmic GB/s |\n|---|---|---|---|---|---|\n")
+        f.write("| `%s` | %d | %.1f | %.1f | %.1f | %.0f |\n\n" % (k["Name"], info["calls"], info["avg_ns"] / 1e3,
+                info["min_ns"] / 1e3, info["max_ns"] / 1e3, info["achieved_GBs_from_trace"]))
+        f.write("PMC (separate passes, per launch): FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB, TCC_EA0_RDREQ %.0f "
+                "(32B: %.0f), TCC_HIT %.0f, TCC_MISS %.0f, TCC_EA0_ATOMIC %.0f\n\n"
+                % (pmc.get("FETCH_SIZE", 0), pmc.get("WRITE_SIZE", 0), pmc.get("TCC_EA0_RDREQ_sum", 0),
+                   pmc.get("TCC_EA0_RDREQ_32B_sum", 0), pmc.get("TCC_HIT_sum", 0), pmc.get("TCC_MISS_sum", 0),
+                   pmc.get("TCC_EA0_ATOMIC_sum", 0)))
+        f.write("HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE = %.3f GB = %.3f x algorithmic (%.3f GB)\n"
+                % (traffic / 1e9, traffic / alg_bytes, alg_bytes / 1e9))
+        if calib:
+            f.write("\nCalibration (loads-only build, every byte read once, same 8 B/lane pattern): FETCH_SIZE %.0f KB "
+                    "=> factor %.3f (the guide's 2.0 is for 16 B/lane)\n"
+                    % (calib["FETCH_SIZE"], info["calibration_factor_for_8B_per_lane"]))
+    print(open(os.path.join(dst, tag + "_summary.md")).read())
+
+
+if __name__ == "__main__":
+    main()
