@@ -169,7 +169,11 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, Plan *pl) {
   // u16 LDS counters: a workgroup may see at most 65535 reads (interleaved
   // slices can get one extra group, hence the margin of `step`)
   if (step * 2 > qk::kMaxReadsPerSlice) return fail(QK_EINVAL, "tile too wide for u16 counters");
-  const uint64_t cap = (qk::kMaxReadsPerSlice - step) / step * step;
+  uint64_t cap = (qk::kMaxReadsPerSlice - step) / step * step;
+  // the kernel addresses a slice with 32-bit byte offsets
+  const uint64_t by_bytes = (0x7FFFFFFFull / std::max<uint32_t>(max_len, 1)) / step * step;
+  if (by_bytes < step) return fail(QK_EINVAL, "reads of %u bytes are too long for one slice", max_len);
+  cap = std::min(cap, by_bytes);
   if (rps > cap) rps = cap;
   pl->reads_per_slice = rps;
   pl->n_slices = (n_reads + rps - 1) / rps;
@@ -229,7 +233,7 @@ int g_ablation_mode = 0;  // set through qk_debug_set_mode (kbench only)
 // Enqueue the kernels of one device-resident batch on `st`.
 int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
                   const uint64_t *d_off, uint32_t *d_hit, uint64_t n_reads,
-                  uint32_t max_len, hipStream_t st) {
+                  uint64_t total_bytes, uint32_t max_len, hipStream_t st) {
   if (n_reads == 0) return QK_OK;
   if (n_reads > 0xFFFFFFF0ull) return fail(QK_EINVAL, "batch too large");
   int rc = grow_table(a, std::max<uint64_t>(max_len, 11));
@@ -251,6 +255,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.kmer_filter = a->d_kmer_filter;
   hp.filter_mask = a->filter_bits ? a->filter_bits - 1 : 0;
   hp.n_reads = n_reads;
+  hp.total_bytes = total_bytes;
   hp.reads_per_slice = pl.reads_per_slice;
   hp.read_len = d_off ? 0 : max_len;
   hp.table_len = (uint32_t)a->table_len;
@@ -469,7 +474,7 @@ int qk_accum_commit(qk_accum *a, uint64_t n_reads, uint64_t total, int offsets_u
   if (offsets_used)
     QK_HIP(hipMemcpyAsync(s.d_off, s.h_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
   rc = enqueue_batch(a, s.d_seq, s.d_qual, offsets_used ? s.d_off : nullptr, s.d_hit,
-                     n_reads, max_len, s.stream);
+                     n_reads, total, max_len, s.stream);
   if (rc) return rc;
   QK_HIP(hipEventRecord(s.done, s.stream));
   s.busy = true;
@@ -533,7 +538,6 @@ int qk_accum_submit_device(qk_accum *a, const void *d_seq, const void *d_qual,
                            const void *d_offsets, uint64_t n_reads, uint64_t total_bytes,
                            uint32_t max_len, void *hip_stream) {
   if (!a || (n_reads && max_len && (!d_seq || !d_qual))) return fail(QK_EINVAL, "NULL argument");
-  (void)total_bytes;
   int rc = set_device(a);
   if (rc) return rc;
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : a->stream;
@@ -550,7 +554,7 @@ int qk_accum_submit_device(qk_accum *a, const void *d_seq, const void *d_qual,
     d_hit = a->d_hit_scratch;
   }
   return enqueue_batch(a, (const uint8_t *)d_seq, (const uint8_t *)d_qual,
-                       (const uint64_t *)d_offsets, d_hit, n_reads, max_len, st);
+                       (const uint64_t *)d_offsets, d_hit, n_reads, total_bytes, max_len, st);
 }
 
 int qk_accum_sync(qk_accum *a) {

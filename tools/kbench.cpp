@@ -35,6 +35,114 @@ extern "C" int qk_debug_set_mode(int mode);
     }                                                                          \
   } while (0)
 
+// reference point: plain streaming read of both arrays, 16 B/lane, grid-stride
+template <int UNROLL>
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *a, const uint4 *b, size_t n16, unsigned *sink) {
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  size_t i = (size_t)blockIdx.x * 256 * UNROLL + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256 * UNROLL;
+  for (; i + 256 * (UNROLL - 1) < n16; i += stride) {
+    uint4 x[UNROLL], y[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) { x[u] = a[i + 256 * u]; y[u] = b[i + 256 * u]; }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      acc.x ^= x[u].x ^ y[u].x; acc.y ^= x[u].y ^ y[u].y; acc.z ^= x[u].z ^ y[u].z; acc.w ^= x[u].w ^ y[u].w;
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) *sink = 1;
+}
+
+// variants isolating what the hist kernel's load pattern costs:
+//  W bytes per lane (8 or 16), T threads, each workgroup streams a contiguous
+//  slice (like hist_kernel) or the grid strides; `skew` shifts every row of
+//  `row` bytes like unaligned 150-byte reads do.
+template <int W, int T, int U, bool SLICE>
+__global__ __launch_bounds__(T) void stream_var_kernel(const uint8_t *a, const uint8_t *b, size_t bytes, unsigned *sink) {
+  unsigned acc = 0;
+  const size_t per_iter = (size_t)T * W * U;
+  size_t n_iter = bytes / per_iter;
+  size_t it0, it1, step;
+  if (SLICE) {
+    size_t per_wg = (n_iter + gridDim.x - 1) / gridDim.x;
+    it0 = blockIdx.x * per_wg; it1 = it0 + per_wg < n_iter ? it0 + per_wg : n_iter; step = 1;
+  } else { it0 = blockIdx.x; it1 = n_iter; step = gridDim.x; }
+  for (size_t it = it0; it < it1; it += step) {
+    const size_t base = it * per_iter + (size_t)threadIdx.x * W;
+    if (W == 16) {
+      uint4 x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { __builtin_memcpy(&x[u], a + base + (size_t)u * T * W, 16); __builtin_memcpy(&y[u], b + base + (size_t)u * T * W, 16); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= x[u].x ^ x[u].y ^ x[u].z ^ x[u].w ^ y[u].x ^ y[u].y ^ y[u].z ^ y[u].w;
+    } else {
+      uint2 x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { __builtin_memcpy(&x[u], a + base + (size_t)u * T * W, 8); __builtin_memcpy(&y[u], b + base + (size_t)u * T * W, 8); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= x[u].x ^ x[u].y ^ y[u].x ^ y[u].y;
+    }
+  }
+  if (acc == 0x12345678u) *sink = 1;
+}
+
+// each lane loads a 16-byte window at an 8-byte stride (windows overlap by 8 B:
+// every word is fetched by two lanes; HBM traffic unchanged, L1 traffic x2)
+template <int T, int U, int LW>
+__global__ __launch_bounds__(T) void stream_overlap_kernel(const uint8_t *a, const uint8_t *b, size_t bytes, unsigned *sink) {
+  unsigned acc = 0;
+  const size_t per_iter = (size_t)T * 8 * U;
+  const size_t n_iter = bytes / per_iter;
+  const size_t per_wg = (n_iter + gridDim.x - 1) / gridDim.x;
+  const size_t it0 = blockIdx.x * per_wg, it1 = it0 + per_wg < n_iter ? it0 + per_wg : n_iter;
+  for (size_t it = it0; it < it1; ++it) {
+    const size_t base = it * per_iter + (size_t)threadIdx.x * 8;
+    if (LW == 16) {
+      uint4 x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { __builtin_memcpy(&x[u], a + base + (size_t)u * T * 8, 16); __builtin_memcpy(&y[u], b + base + (size_t)u * T * 8, 16); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= x[u].x ^ x[u].y ^ x[u].z ^ x[u].w ^ y[u].x ^ y[u].y ^ y[u].z ^ y[u].w;
+    } else {  // 12-byte window: dwordx3
+      struct u3 { unsigned x, y, z; };
+      u3 x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { __builtin_memcpy(&x[u], a + base + (size_t)u * T * 8, 12); __builtin_memcpy(&y[u], b + base + (size_t)u * T * 8, 12); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= x[u].x ^ x[u].y ^ x[u].z ^ y[u].x ^ y[u].y ^ y[u].z;
+    }
+  }
+  if (acc == 0x12345678u) *sink = 1;
+}
+
+template <int T, int U, int LW>
+static void run_overlap(const char *name, const uint8_t *a, const uint8_t *b, size_t bytes, unsigned *sink, int grid) {
+  hipEvent_t e0, e1;
+  HK(hipEventCreate(&e0)); HK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    HK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((stream_overlap_kernel<T, U, LW>), dim3(grid), dim3(T), 0, 0, a, b, bytes, sink);
+    HK(hipEventRecord(e1, 0));
+    HK(hipEventSynchronize(e1));
+    float ms; HK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep) printf("  %-44s grid %5d: %.3f ms  %.2f TB/s\n", name, grid, ms / 20, 2.0 * bytes / (ms / 20 * 1e-3) / 1e12);
+  }
+}
+
+template <int W, int T, int U, bool SLICE>
+static void run_var(const char *name, const uint8_t *a, const uint8_t *b, size_t bytes, unsigned *sink, int grid) {
+  hipEvent_t e0, e1;
+  HK(hipEventCreate(&e0)); HK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    HK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((stream_var_kernel<W, T, U, SLICE>), dim3(grid), dim3(T), 0, 0, a, b, bytes, sink);
+    HK(hipEventRecord(e1, 0));
+    HK(hipEventSynchronize(e1));
+    float ms; HK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep) printf("  %-44s grid %5d: %.3f ms  %.2f TB/s\n", name, grid, ms / 20, 2.0 * bytes / (ms / 20 * 1e-3) / 1e12);
+  }
+}
+
 static inline uint64_t splitmix(uint64_t &s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -92,7 +200,10 @@ int main(int argc, char **argv) {
   uint8_t *d_seq, *d_qual;
   uint64_t *d_off = nullptr;
   HK(hipMalloc((void **)&d_seq, total + QK_TAIL_SLACK));
-  HK(hipMalloc((void **)&d_qual, total + QK_TAIL_SLACK));
+  size_t qual_shift = getenv("KB_QUAL_SHIFT") ? strtoull(getenv("KB_QUAL_SHIFT"), 0, 10) : 0;
+  HK(hipMalloc((void **)&d_qual, total + QK_TAIL_SLACK + qual_shift));
+  d_qual += qual_shift;
+  printf("d_seq %p d_qual %p (shift %zu)\n", (void *)d_seq, (void *)d_qual, qual_shift);
   HK(hipMemcpy(d_seq, seq.data(), total + QK_TAIL_SLACK, hipMemcpyHostToDevice));
   HK(hipMemcpy(d_qual, qual.data(), total + QK_TAIL_SLACK, hipMemcpyHostToDevice));
   if (ragged) {
@@ -146,6 +257,50 @@ int main(int argc, char **argv) {
     if (bad) return 1;
   }
 
+  // ---- streaming-read reference point ------------------------------------
+  if (!ragged) {
+    unsigned *d_sink;
+    HK(hipMalloc((void **)&d_sink, 4));
+    const size_t n16 = total / 16;
+    hipEvent_t e0, e1;
+    HK(hipEventCreate(&e0));
+    HK(hipEventCreate(&e1));
+    for (int grid : {2048, 4096, 8192}) {
+      for (int rep = 0; rep < 2; ++rep) {
+        HK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 10; ++i)
+          hipLaunchKernelGGL(stream_read_kernel<4>, dim3(grid), dim3(256), 0, 0, (const uint4 *)d_seq, (const uint4 *)d_qual, n16, d_sink);
+        HK(hipEventRecord(e1, 0));
+        HK(hipEventSynchronize(e1));
+        float ms;
+        HK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("stream_read 16B/lane grid=%d: %.3f ms per pass, %.2f TB/s\n", grid, ms / 10, 2.0 * n16 * 16 / (ms / 10 * 1e-3) / 1e12);
+      }
+    }
+  }
+
+  if (!ragged && getenv("KB_STREAM_VARIANTS")) {
+    unsigned *d_sink; HK(hipMalloc((void **)&d_sink, 4));
+    size_t bytes = total / 65536 * 65536;
+    run_var<16, 256, 4, false>("16B/lane T=256 U=4 grid-stride", d_seq, d_qual, bytes, d_sink, 2048);
+    run_var<8, 256, 4, false>("8B/lane T=256 U=4 grid-stride", d_seq, d_qual, bytes, d_sink, 2048);
+    run_var<8, 256, 8, false>("8B/lane T=256 U=8 grid-stride", d_seq, d_qual, bytes, d_sink, 2048);
+    run_var<8, 1024, 4, false>("8B/lane T=1024 U=4 grid-stride", d_seq, d_qual, bytes, d_sink, 512);
+    run_var<8, 1024, 4, true>("8B/lane T=1024 U=4 slice/WG", d_seq, d_qual, bytes, d_sink, 512);
+    run_var<16, 1024, 4, true>("16B/lane T=1024 U=4 slice/WG", d_seq, d_qual, bytes, d_sink, 512);
+    run_var<16, 1024, 2, true>("16B/lane T=1024 U=2 slice/WG", d_seq, d_qual, bytes, d_sink, 512);
+    run_var<8, 1024, 4, true>("8B/lane T=1024 U=4 slice/WG +6B skew", d_seq + 6, d_qual + 6, bytes - 65536, d_sink, 512);
+    run_var<16, 1024, 4, true>("16B/lane T=1024 U=4 slice/WG +6B skew", d_seq + 6, d_qual + 6, bytes - 65536, d_sink, 512);
+    run_var<8, 1024, 8, true>("8B/lane T=1024 U=8 slice/WG", d_seq, d_qual, bytes, d_sink, 512);
+    run_var<8, 512, 4, true>("8B/lane T=512 U=4 slice/WG", d_seq, d_qual, bytes, d_sink, 1024);
+    run_var<8, 1024, 4, true>("8B/lane T=1024 U=4 slice/WG grid 256", d_seq, d_qual, bytes, d_sink, 256);
+    run_overlap<1024, 4, 16>("16B window @8B stride (aligned 8) U=4", d_seq, d_qual, bytes - 65536, d_sink, 512);
+    run_overlap<1024, 2, 16>("16B window @8B stride (aligned 8) U=2", d_seq, d_qual, bytes - 65536, d_sink, 512);
+    run_overlap<1024, 4, 12>("12B window @8B stride (aligned 8) U=4", d_seq, d_qual, bytes - 65536, d_sink, 512);
+    run_overlap<1024, 4, 12>("12B window @8B stride (aligned 4: +4)", d_seq + 4, d_qual + 4, bytes - 65536, d_sink, 512);
+    run_overlap<512, 4, 16>("16B window @8B stride T=512 U=4", d_seq, d_qual, bytes - 65536, d_sink, 1024);
+  }
+
   // ---- sweep -------------------------------------------------------------
   struct Cfg { int T, U, tile, wgs; };
   std::vector<Cfg> cfgs = {
@@ -171,10 +326,12 @@ int main(int argc, char **argv) {
         qk_accum_destroy(acc);
         continue;
       }
-      CK(qk_accum_submit_device(acc, d_seq, d_qual, d_off, n_reads, total, max_len, nullptr));
+      // warm up for ~100 ms so the clocks have ramped before anything is timed
+      for (int i = 0; i < (int)(0.1 / (total * 4e-13)) + 2; ++i)
+        CK(qk_accum_submit_device(acc, d_seq, d_qual, d_off, n_reads, total, max_len, nullptr));
       CK(qk_accum_sync(acc));
       CK(qk_accum_timing_enable(acc, 1));
-      const int iters = 10;
+      const int iters = 20;
       auto t0 = std::chrono::steady_clock::now();
       for (int i = 0; i < iters; ++i)
         CK(qk_accum_submit_device(acc, d_seq, d_qual, d_off, n_reads, total, max_len, nullptr));
