@@ -7,8 +7,8 @@
 // i < l.  The parallel form tests every window independently and takes a
 // per-read minimum:
 //   scan kernel : lane owns 16 positions, rebuilds the 2-bit codes of those and
-//                 the 9 preceding bases, tests each window against a 16 KiB
-//                 LDS-resident pre-filter (hash = low 17 bits of the 20-bit
+//                 the 9 preceding bases, tests each window against a 32 KiB
+//                 LDS-resident pre-filter (hash = low 18 bits of the 20-bit
 //                 index) and, on a filter hit only, the exact 2^20-bit table
 //                 in global memory (L2 resident); atomicMin(first_hit[read]).
 //   count kernel: one thread per read turns first_hit into the kmer_count
@@ -21,8 +21,7 @@
 
 namespace qk {
 
-constexpr uint32_t kFilterBits = 1u << 17;  // 16 KiB of LDS
-constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+constexpr uint32_t kFilterBits = 1u << kFusedFilterLog2;  // 32 KiB of LDS, shared with the fused path
 constexpr int kScanThreads = 256;
 constexpr int kCountThreads = 256;
 constexpr uint32_t kCountLdsPos = 4096;
@@ -125,6 +124,17 @@ __global__ __launch_bounds__(kCountThreads) void adapter_count_kernel(const Hist
   }
 }
 
+inline int launch_adapter_count(const HistParams &hp, int n_cu, hipStream_t st) {
+  if (hp.n_reads == 0) return 0;
+  uint64_t cblocks = (hp.n_reads + kCountThreads - 1) / kCountThreads;
+  if (cblocks > (uint64_t)n_cu * 4) cblocks = (uint64_t)n_cu * 4;
+  if (hp.offsets == nullptr)
+    hipLaunchKernelGGL(adapter_count_kernel<true>, dim3((unsigned)cblocks), dim3(kCountThreads), 0, st, hp);
+  else
+    hipLaunchKernelGGL(adapter_count_kernel<false>, dim3((unsigned)cblocks), dim3(kCountThreads), 0, st, hp);
+  return (int)hipGetLastError();
+}
+
 // returns a hipError_t as int
 inline int launch_adapter_scan(const HistParams &hp, int n_cu, hipStream_t st) {
   if (hp.n_reads == 0) return 0;
@@ -145,13 +155,7 @@ inline int launch_adapter_scan(const HistParams &hp, int n_cu, hipStream_t st) {
     hipLaunchKernelGGL(adapter_scan_kernel<false>, dim3((unsigned)blocks), dim3(kScanThreads), 0, st, hp, lpr, max_chunks);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  uint64_t cblocks = (hp.n_reads + kCountThreads - 1) / kCountThreads;
-  if (cblocks > (uint64_t)n_cu * 4) cblocks = (uint64_t)n_cu * 4;
-  if (fixed)
-    hipLaunchKernelGGL(adapter_count_kernel<true>, dim3((unsigned)cblocks), dim3(kCountThreads), 0, st, hp);
-  else
-    hipLaunchKernelGGL(adapter_count_kernel<false>, dim3((unsigned)cblocks), dim3(kCountThreads), 0, st, hp);
-  return (int)hipGetLastError();
+  return launch_adapter_count(hp, n_cu, st);
 }
 
 // Upload the exact bitset and derive the LDS pre-filter from it.

@@ -22,6 +22,13 @@
 //     (Measured: LDS *instruction issue*, ~7 cycles per ds_add wave-instruction
 //     per CU, is the binding resource, not the LDS array — two atomics per
 //     base cost 2x one.)
+//   * adapter first hit (ADAPT builds, single-tile batches; quack.c:206-217):
+//     the SWAR indicators give 2-bit codes, 8 of them packed per chunk; the 9
+//     predecessor codes come from lanes -1 / -2 by DPP wave_shr:1 (two feeder
+//     lanes per wave re-compute the previous wave's last chunks); each of the 8
+//     windows is tested against an LDS-resident bit filter keyed by its low
+//     bits, and only filter hits consult the exact 2^20-bit table;
+//     atomicMin(first_hit[read]).
 // Quality rows are raw byte values (& 127); the mapping to quack's 91 score
 // bins is applied once, at flush time (histograms are linear, so re-binning
 // afterwards is exact).
@@ -56,7 +63,8 @@ struct HistParams {
   uint32_t tile_pos;            // positions per tile (multiple of 8)
   uint32_t ch;                  // chunks per tile = tile_pos / 8
   uint32_t row_dwords;          // LDS row stride: 4*ch rounded up to 32 banks
-  uint32_t reads_per_iter;      // T / ch
+  uint32_t reads_per_iter;      // chunk lanes per workgroup / ch
+  uint32_t n_slices;            // read slices (grid = n_tiles * n_slices rounded to 8)
   uint32_t no_adapters;         // kmers == NULL semantics (quack.c:210,215)
   uint32_t filter_mask;         // bits in kmer_filter - 1
 };
@@ -97,19 +105,32 @@ constexpr uint32_t kKeyT = 0x14141414u, kKeyC = 0x03030303u, kKeyG = 0x07070707u
 // LDS image (dwords): quality histogram [128][row_dwords] | base counters
 // [4: valid,T,C,G][8*ch] | length_count [8*ch] | misc[4]
 inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch) { return (4u * ch + 31u) / 32u * 32u; }
-inline size_t hist_lds_bytes(uint32_t ch) {
-  return ((size_t)kQRows * hist_row_dwords(ch) + 5u * 8u * ch + 4u) * sizeof(uint32_t);
+constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit window filter = 32 KiB of LDS
+constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u;
+constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false) {
+  return ((size_t)kQRows * hist_row_dwords(ch) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords : 0u)) * sizeof(uint32_t);
+}
+
+// value of the same register in lane-1 (v_mov_b32_dpp wave_shr:1); lane 0 gets 0
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
 }
 
 // MODE: 0 full; 1 loads only; 2 quality only; 3 bases only (ablation builds
 // used by tools/kbench only; the shim always launches MODE 0).
-template <int T, int U, bool FIXED, int MODE>
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false>
 __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
   extern __shared__ uint32_t lds[];
   const uint32_t tid = threadIdx.x;
   const uint32_t CH = p.ch;
-  const uint32_t tile = blockIdx.x % p.n_tiles;
-  const uint32_t slice = blockIdx.x / p.n_tiles;
+  // blocks b and b+8 share an XCD (round-robin dispatch): give them the tiles
+  // of ONE read slice, so the cache lines two tiles share are fetched into one
+  // L2.  Purely a speed choice; any placement is correct.
+  const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+  const uint32_t tile = k % p.n_tiles;
+  const uint32_t slice = (k / p.n_tiles) * 8u + xcd;
+  if (slice >= p.n_slices) return;
   const uint32_t P0 = tile * p.tile_pos;
   const uint32_t RD = p.row_dwords;
   const uint32_t TP = 8u * CH;  // == p.tile_pos
@@ -118,13 +139,25 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
   uint32_t *lds_len = lds_base + 4u * TP;
   uint32_t *lds_misc = lds_len + TP;
 
+  uint32_t *lds_filter = lds_misc + 4u;   // ADAPT only
+  const uint8_t *filt8 = reinterpret_cast<const uint8_t *>(lds_filter);
+
   for (uint32_t i = tid; i < hist_words + 5u * TP + 4u; i += T) lds[i] = 0;
+  if (ADAPT)
+    for (uint32_t i = tid; i < kFusedFilterWords; i += T) lds_filter[i] = p.kmer_filter[i];
   __syncthreads();
 
-  const uint32_t ri = tid / CH;
-  const uint32_t ch = tid - ri * CH;
+  // ADAPT: lanes 0 and 1 of every wave are feeders: they recompute the chunks
+  // of the previous wave's lanes 62/63 so that lanes 2/3 find their
+  // predecessors' codes by DPP; they take no part in the histograms.
+  const uint32_t lane_id = tid & 63u;
+  const uint32_t feeders = ADAPT ? 2u : 0u;
+  const int32_t slot_signed = (int32_t)((tid >> 6) * (64u - feeders) + lane_id) - (int32_t)feeders;
+  const uint32_t slot = slot_signed < 0 ? 0u : (uint32_t)slot_signed;
+  const uint32_t ri = slot / CH;
+  const uint32_t ch = slot - ri * CH;
   const uint32_t RW = p.reads_per_iter;
-  const bool lane_on = ri < RW;
+  const bool lane_on = lane_id >= feeders && ri < RW;
   const uint32_t cpos = P0 + 8u * ch;   // first position of the owned chunk
   const uint32_t row_bytes = 4u * RD;   // a multiple of 128 B: bank == column
   uint32_t qcol[4];
@@ -151,6 +184,8 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
   const uint64_t room = p.total_bytes - base_al;   // total_bytes >= base_al when slice_reads > 0
   const uint32_t off_limit = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
   const uint32_t cposp = cpos + (uint32_t)(slice_base & 3ull);
+  // windows ending before position 9 do not exist
+  const uint32_t win_mask = cpos >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cpos)) - 1u));
 
   uint32_t n_gt10 = 0;   // reads longer than 10 (kmers==NULL path, quack.c:215)
   uint32_t keep = 0;     // MODE 1 only
@@ -224,6 +259,10 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
       // bytes past the end of the read -> 0xFF: quality row 127 is discarded
       // at flush time, and 0xFF & 31 matches none of T/C/G.
       const uint32_t n = nv[u];
+      // nothing of these reads reaches this tile (ragged batches, long reads):
+      // the whole wave moves on.  ADAPT needs every lane's codes, but then no
+      // lane has a valid window either.
+      if (!FIXED && __builtin_amdgcn_ballot_w64(n != 0) == 0) continue;
       const uint2 qa = window8(q[u], sk[u]);
       const uint2 sa = window8(s[u], sk[u]);
       const uint32_t m0 = n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n));
@@ -244,12 +283,63 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
         }
       }
       if (MODE == 0 || MODE == 3) {
+        // letter indicators come from the UNMASKED bytes when the adapter scan
+        // needs them (feeder lanes and chunk tails must still yield the real
+        // codes; window validity is enforced by `hits` masks below) and are
+        // masked per byte for the content counters
+        uint32_t et[2], ec[2], eg[2];
+        const uint32_t raw[2] = {sa.x, sa.y};
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          acc_v[d] += ~mk[d] & 0x01010101u;
-          acc_t[d] += swar_eq(sw[d], kKeyT);
-          acc_c[d] += swar_eq(sw[d], kKeyC);
-          acc_g[d] += swar_eq(sw[d], kKeyG);
+          const uint32_t valid01 = ~mk[d] & 0x01010101u;
+          const uint32_t src = ADAPT ? raw[d] : sw[d];
+          et[d] = swar_eq(src, kKeyT);
+          ec[d] = swar_eq(src, kKeyC);
+          eg[d] = swar_eq(src, kKeyG);
+          acc_v[d] += valid01;
+          acc_t[d] += ADAPT ? (et[d] & valid01) : et[d];
+          acc_c[d] += ADAPT ? (ec[d] & valid01) : ec[d];
+          acc_g[d] += ADAPT ? (eg[d] & valid01) : eg[d];
+        }
+        if (ADAPT) {
+          // 2-bit codes A0 T1 C2 G3 (quack.c:150) of the 8 owned bases, first
+          // base most significant: byte codes -> 8 bits per dword by multiply
+          uint32_t c8[2];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const uint32_t cb = ((ec[d] + eg[d]) << 1) + (et[d] + eg[d]);
+            c8[d] = (cb * 0x40100401u) >> 24;
+          }
+          const uint32_t own16 = (c8[0] << 8) | c8[1];
+          const uint32_t prev16 = from_prev_lane(own16);   // positions cpos-8 .. cpos-1
+          const uint32_t prev2 = from_prev_lane(prev16);   // its low code: position cpos-9
+          const uint32_t plo = (prev16 << 16) | own16;
+          // window ending at owned position j = bits [2*(7-j), 2*(7-j)+20) of
+          // {prev2&3, plo}; the filter is keyed by the window's low 18 bits
+          uint32_t hits = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int sh = 2 * (7 - j);
+            const uint32_t byte = filt8[__builtin_amdgcn_ubfe(plo, sh + 3, kFusedFilterLog2 - 3)];
+            hits |= __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(plo, sh, 3), 1) << j;
+          }
+          // only windows that end inside the read, at e >= 9 (quack.c:206-213)
+          hits &= (1u << n) - 1u;
+          hits &= win_mask;
+          if (hits) {
+            uint32_t best = kNoHit;
+            while (hits) {
+              const int j = __builtin_ctz(hits);
+              hits &= hits - 1u;
+              const uint32_t km = (uint32_t)(((((uint64_t)(prev2 & 3u)) << 32) | plo) >> (2 * (7 - j))) & 0xFFFFFu;
+              if ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) {
+                best = cpos + (uint32_t)j;
+                break;
+              }
+            }
+            if (best != kNoHit)
+              atomicMin(&p.first_hit[r_begin + it + (uint32_t)u * RW + ri], best);
+          }
         }
       }
     }

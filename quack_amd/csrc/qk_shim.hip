@@ -89,7 +89,7 @@ struct qk_accum {
   uint32_t *d_hit_scratch = nullptr;  // first-hit buffer for device submits
   uint64_t hit_scratch_reads = 0;
   // tuning
-  int threads = 1024, unroll = 4, tile = 192, wgs_per_cu = 2;
+  int threads = 1024, unroll = 4, tile = 0, wgs_per_cu = 0;   // 0 = automatic
   // timing
   bool timing = false;
   std::vector<TimedLaunch> timed;
@@ -146,45 +146,71 @@ int grow_table(qk_accum *a, uint64_t need) {
 struct Plan {
   uint32_t n_tiles, tile_pos, ch, rw;
   uint64_t reads_per_slice, n_slices;
+  bool fused_adapters;
 };
 
+// Launch geometry.  One position tile whenever the LDS histogram of the whole
+// read fits (<= 576 positions, 448 with the adapter filter resident): tiles of
+// one read live in different workgroups and share cache lines at the seams
+// (measured on 300 bp: two 152-wide tiles 1.78 ms, one 304-wide tile 1.10 ms).
+// Longer reads get tiles of <= 512 positions.  The grid is sized to residency:
+// workgroups per CU = what the LDS admits (at most 2 of 1024 threads).
 int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, Plan *pl) {
   const uint32_t T = (uint32_t)a->threads, U = (uint32_t)a->unroll;
-  uint32_t max_tile = (uint32_t)a->tile;
-  max_tile = std::max<uint32_t>(8, max_tile / 8 * 8);
-  if (max_tile / 8 > T) max_tile = T * 8;
-  uint32_t n_tiles = (max_len + max_tile - 1) / max_tile;
-  if (n_tiles == 0) n_tiles = 1;
+  const uint32_t single_cap = a->adapters ? 448u : 576u;
+  uint32_t cap = a->tile > 0 ? std::max<uint32_t>(8, (uint32_t)a->tile / 8 * 8) : single_cap;
+  cap = std::min(cap, single_cap);
+  uint32_t n_tiles = std::max<uint32_t>(1, (max_len + cap - 1) / cap);
+  if (n_tiles > 1 && cap > 512) {
+    cap = 512;
+    n_tiles = (max_len + cap - 1) / cap;
+  }
+  pl->fused_adapters = a->adapters && n_tiles == 1 && !getenv("QUACK_HIP_UNFUSED_ADAPTERS");
+  const uint32_t lanes = pl->fused_adapters ? T / 64 * 62 : T;   // two feeder lanes per wave when fused
+  if (cap / 8 > lanes) {
+    cap = lanes * 8;
+    n_tiles = (max_len + cap - 1) / cap;
+    if (n_tiles > 1) pl->fused_adapters = false;
+  }
   uint32_t tile_pos = (uint32_t)round_up((max_len + n_tiles - 1) / n_tiles, 8);
   if (tile_pos == 0) tile_pos = 8;
   pl->n_tiles = n_tiles;
   pl->tile_pos = tile_pos;
   pl->ch = tile_pos / 8;
-  pl->rw = T / pl->ch;
+  pl->rw = (pl->fused_adapters ? T / 64 * 62 : T) / pl->ch;
   const uint64_t step = (uint64_t)pl->rw * U;
-  uint64_t target = (uint64_t)a->n_cu * a->wgs_per_cu;
+  const size_t lds = qk::hist_lds_bytes(pl->ch, pl->fused_adapters);
+  if (lds > 160 * 1024) return fail(QK_EINVAL, "LDS tile too large (%zu bytes)", lds);
+  uint32_t wgs = a->wgs_per_cu > 0 ? (uint32_t)a->wgs_per_cu
+                                   : std::max<uint32_t>(1, std::min<uint32_t>(2048 / T, (uint32_t)(160 * 1024 / lds)));
+  // single tile: one resident wave of workgroups.  Several tiles: reads do not
+  // reach the far tiles equally, so over-decompose 4x and let the dispatcher
+  // balance (slices in multiples of 8, one per XCD).
+  uint64_t target = (uint64_t)a->n_cu * wgs * (n_tiles > 1 ? 4 : 1);
   uint64_t n_slices = std::max<uint64_t>(1, target / n_tiles);
+  if (n_tiles > 1) n_slices = round_up(n_slices, 8);
   uint64_t rps = (n_reads + n_slices - 1) / n_slices;
   rps = round_up(std::max<uint64_t>(rps, 1), step);
-  // u16 LDS counters: a workgroup may see at most 65535 reads (interleaved
-  // slices can get one extra group, hence the margin of `step`)
+  // u16 LDS counters: a workgroup may see at most 65535 reads
   if (step * 2 > qk::kMaxReadsPerSlice) return fail(QK_EINVAL, "tile too wide for u16 counters");
-  uint64_t cap = (qk::kMaxReadsPerSlice - step) / step * step;
+  uint64_t rcap = (qk::kMaxReadsPerSlice - step) / step * step;
   // the kernel addresses a slice with 32-bit byte offsets
   const uint64_t by_bytes = (0x7FFFFFFFull / std::max<uint32_t>(max_len, 1)) / step * step;
   if (by_bytes < step) return fail(QK_EINVAL, "reads of %u bytes are too long for one slice", max_len);
-  cap = std::min(cap, by_bytes);
-  if (rps > cap) rps = cap;
+  rcap = std::min(rcap, by_bytes);
+  if (rps > rcap) rps = rcap;
   pl->reads_per_slice = rps;
   pl->n_slices = (n_reads + rps - 1) / rps;
   return QK_OK;
 }
 
 template <int T, int U>
-int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, dim3 grid,
+int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, dim3 grid,
                    size_t lds, hipStream_t st) {
   void (*k)(const qk::HistParams) = nullptr;
-  if (fixed) {
+  if (adapt) {
+    if (mode == 0) k = fixed ? qk::hist_kernel<T, U, true, 0, true> : qk::hist_kernel<T, U, false, 0, true>;
+  } else if (fixed) {
     switch (mode) {
       case 0: k = qk::hist_kernel<T, U, true, 0>; break;
 #ifdef QK_ABLATION
@@ -203,13 +229,12 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, dim3 grid,
   return QK_OK;
 }
 
-int launch_hist(qk_accum *a, const qk::HistParams &hp, bool fixed, int mode,
+int launch_hist(qk_accum *a, const qk::HistParams &hp, bool fixed, int mode, bool adapt,
                 uint64_t n_blocks, hipStream_t st) {
-  const size_t lds = qk::hist_lds_bytes(hp.ch);
-  if (lds > 160 * 1024) return fail(QK_EINVAL, "LDS tile too large (%zu bytes)", lds);
+  const size_t lds = qk::hist_lds_bytes(hp.ch, adapt);
   dim3 grid((unsigned)n_blocks);
 #define QK_TU(TT, UU) \
-  if (a->threads == TT && a->unroll == UU) return launch_hist_tu<TT, UU>(hp, fixed, mode, grid, lds, st);
+  if (a->threads == TT && a->unroll == UU) return launch_hist_tu<TT, UU>(hp, fixed, mode, adapt, grid, lds, st);
   QK_TU(1024, 4) QK_TU(1024, 2) QK_TU(1024, 1)
   QK_TU(512, 4) QK_TU(512, 2) QK_TU(512, 1)
   QK_TU(256, 4) QK_TU(256, 2)
@@ -263,6 +288,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.tile_pos = pl.tile_pos;
   hp.ch = pl.ch;
   hp.reads_per_iter = pl.rw;
+  hp.n_slices = (uint32_t)pl.n_slices;
   hp.row_dwords = qk::hist_row_dwords(pl.ch);
   hp.no_adapters = a->adapters ? 0 : 1;
 
@@ -273,15 +299,17 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     if (!tl.t0 || !tl.t1) return fail(QK_EHIP, "hipEventCreate failed");
     QK_HIP(hipEventRecord(tl.t0, st));
   }
-  rc = launch_hist(a, hp, d_off == nullptr, g_ablation_mode,
-                   pl.n_slices * pl.n_tiles, st);
+  if (pl.fused_adapters) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
+  rc = launch_hist(a, hp, d_off == nullptr, g_ablation_mode, pl.fused_adapters,
+                   round_up(pl.n_slices, 8) * pl.n_tiles, st);
   if (rc) return rc;
   if (a->timing) {
     QK_HIP(hipEventRecord(tl.t1, st));
     a->timed.push_back(tl);
   }
   if (a->adapters) {
-    rc = qk::launch_adapter_scan(hp, a->n_cu, st);
+    // fused: the histogram pass already left first_hit[]; otherwise scan now
+    rc = pl.fused_adapters ? qk::launch_adapter_count(hp, a->n_cu, st) : qk::launch_adapter_scan(hp, a->n_cu, st);
     if (rc) return fail(QK_EHIP, "adapter kernels failed: %s", hipGetErrorString((hipError_t)rc));
   }
   a->n_reads += n_reads;
