@@ -214,9 +214,34 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
     since_spill = 0;
   };
 
+  // ragged batches: the start/end offsets of the NEXT iteration's reads are
+  // requested while the current iteration is processed, so the data loads never
+  // wait on an offsets round trip
+  uint64_t nx0[U], nx1[U];
+  auto fetch_offsets = [&](uint32_t it_next) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t rel = it_next + (uint32_t)u * RW + ri;
+      const uint32_t i0 = rel < idx_limit ? rel : idx_limit;
+      const uint32_t i1 = i0 < idx_limit ? i0 + 1u : idx_limit;
+      nx0[u] = obase[i0];
+      nx1[u] = obase[i1];
+    }
+  };
+  if (!FIXED && slice_reads) fetch_offsets(0);
+
   for (uint32_t it = 0; it < slice_reads; it += RW * U) {
     u32x3 q[U], s[U];
     uint32_t nv[U], sk[U];
+    uint64_t cur0[U], cur1[U];
+    if (!FIXED) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        cur0[u] = nx0[u];
+        cur1[u] = nx1[u];
+      }
+      if (it + RW * U < slice_reads) fetch_offsets(it + RW * U);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t rel = it + (uint32_t)u * RW + ri;   // read index within the slice
@@ -226,20 +251,30 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
         off = rel * p.read_len + cposp;
         len = p.read_len;
       } else {
-        const uint32_t i0 = rel < idx_limit ? rel : idx_limit;
-        const uint32_t i1 = i0 < idx_limit ? i0 + 1u : idx_limit;
-        const uint64_t o0 = obase[i0];
-        len = (uint32_t)(obase[i1] - o0);
-        off = (uint32_t)(o0 - base_al) + cpos;
+        len = (uint32_t)(cur1[u] - cur0[u]);
+        off = (uint32_t)(cur0[u] - base_al) + cpos;
       }
-      uint32_t n = (ok && len > cpos) ? len - cpos : 0u;
-      n = n > 8u ? 8u : n;
-      nv[u] = n;
+      // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
+      // compute codes like their originals but count nothing
+      uint32_t n_raw = (rel < slice_reads && ri < RW && len > cpos) ? len - cpos : 0u;
+      n_raw = n_raw > 8u ? 8u : n_raw;
+      nv[u] = lane_on ? n_raw : 0u;
       off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
       sk[u] = off & 3u;
       off &= ~3u;
-      q[u] = load12_aligned(qbase + off);
-      s[u] = load12_aligned(sbase + off);
+      if (FIXED) {
+        q[u] = load12_aligned(qbase + off);
+        s[u] = load12_aligned(sbase + off);
+      } else {
+        // ragged: chunks past the end of their read fetch nothing (for 1-20 kb
+        // reads that is a third of all chunk slots)
+        q[u] = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        s[u] = q[u];
+        if (n_raw != 0) {
+          q[u] = load12_aligned(qbase + off);
+          s[u] = load12_aligned(sbase + off);
+        }
+      }
       if (!FIXED) {
         // length_count / kmers==NULL bookkeeping by the owner of chunk 0
         if (ok && ch == 0 && tile == 0) {

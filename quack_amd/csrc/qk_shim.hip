@@ -181,8 +181,10 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, Plan *pl) {
   const uint64_t step = (uint64_t)pl->rw * U;
   const size_t lds = qk::hist_lds_bytes(pl->ch, pl->fused_adapters);
   if (lds > 160 * 1024) return fail(QK_EINVAL, "LDS tile too large (%zu bytes)", lds);
+  // residency: the kernels need 89-104 VGPRs, i.e. 4 waves per SIMD = 1024
+  // threads per CU, and the LDS image must fit as many times
   uint32_t wgs = a->wgs_per_cu > 0 ? (uint32_t)a->wgs_per_cu
-                                   : std::max<uint32_t>(1, std::min<uint32_t>(2048 / T, (uint32_t)(160 * 1024 / lds)));
+                                   : std::max<uint32_t>(1, std::min<uint32_t>(1024 / T, (uint32_t)(160 * 1024 / lds)));
   // single tile: one resident wave of workgroups.  Several tiles: reads do not
   // reach the far tiles equally, so over-decompose 4x and let the dispatcher
   // balance (slices in multiples of 8, one per XCD).
