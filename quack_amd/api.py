@@ -206,6 +206,14 @@ class Accumulator:
         return SequenceData(out, b.value)
 
 
+def allreduce(accumulators):
+    """qk_accum_allreduce: sum the tables of several accumulators in one process
+    (same-device shards by an add kernel, distinct devices by one RCCL
+    all-reduce); afterwards each holds the global table."""
+    arr = (ctypes.c_void_p * len(accumulators))(*[a._h for a in accumulators])
+    _check(_capi.hip().qk_accum_allreduce(arr, len(accumulators)))
+
+
 def pad_for_device(arr):
     """numpy uint8 array + the tail slack the kernels may read past the end."""
     out = np.zeros(len(arr) + QK_TAIL_SLACK, dtype=np.uint8)

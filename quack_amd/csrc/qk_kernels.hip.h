@@ -439,4 +439,9 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
   }
 }
 
+// dst += src over the planar tables of two accumulators on the same device
+__global__ __launch_bounds__(256) void table_add_kernel(unsigned long long *dst, const unsigned long long *src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
+}
+
 }  // namespace qk

@@ -679,7 +679,37 @@ int qk_accum_allreduce(qk_accum **accs, int n) {
     if ((rc = grow_table(accs[i], table_len))) return rc;
     if (accs[i]->table_len != table_len) return fail(QK_ESTATE, "table sizes diverged");
   }
-  if (n > 1) {
+  const size_t words = (size_t)QK_N_ROWS * table_len;
+  // 1) accumulators that share a device are summed into that device's first
+  //    one (the "leader") with a plain add kernel — no collective needed
+  std::vector<int> leader(n);
+  std::vector<int> leaders;
+  for (int i = 0; i < n; ++i) {
+    leader[i] = i;
+    for (int j = 0; j < i; ++j)
+      if (accs[j]->device == accs[i]->device) {
+        leader[i] = leader[j];
+        break;
+      }
+    if (leader[i] == i) leaders.push_back(i);
+  }
+  for (int i = 0; i < n; ++i) {
+    if (leader[i] == i) continue;
+    qk_accum *dst = accs[leader[i]];
+    int rc = set_device(dst);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 4096);
+    hipLaunchKernelGGL(qk::table_add_kernel, dim3(blocks), dim3(256), 0, dst->stream, dst->d_table, accs[i]->d_table, words);
+    QK_HIP(hipGetLastError());
+  }
+  for (int l : leaders) {
+    int rc = set_device(accs[l]);
+    if (rc) return rc;
+    QK_HIP(hipStreamSynchronize(accs[l]->stream));
+  }
+  // 2) distinct devices: ONE all-reduce of the integer tables over xGMI
+  const int nl = (int)leaders.size();
+  if (nl > 1) {
     static void *lib = nullptr;
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -692,28 +722,34 @@ int qk_accum_allreduce(qk_accum **accs, int n) {
     fn_ErrStr errstr = (fn_ErrStr)dlsym(lib, "ncclGetErrorString");
     if (!init || !allreduce || !gstart || !gend || !cdestroy || !errstr)
       return fail(QK_ERCCL, "librccl.so lacks a required symbol");
-    std::vector<ncclComm_t> comms(n);
-    std::vector<int> devs(n);
-    for (int i = 0; i < n; ++i) devs[i] = accs[i]->device;
-    int e = init(comms.data(), n, devs.data());
+    std::vector<ncclComm_t> comms(nl);
+    std::vector<int> devs(nl);
+    for (int i = 0; i < nl; ++i) devs[i] = accs[leaders[i]]->device;
+    int e = init(comms.data(), nl, devs.data());
     if (e) return fail(QK_ERCCL, "ncclCommInitAll: %s", errstr(e));
-    const size_t words = (size_t)QK_N_ROWS * table_len;
     const int kNcclUint64 = 5, kNcclSum = 0;  // rccl.h: ncclUint64 = 5, ncclSum = 0
     e = gstart();
-    for (int i = 0; i < n && !e; ++i) {
-      (void)hipSetDevice(accs[i]->device);
-      e = allreduce(accs[i]->d_table, accs[i]->d_table, words, kNcclUint64, kNcclSum, comms[i], accs[i]->stream);
+    for (int i = 0; i < nl && !e; ++i) {
+      qk_accum *a = accs[leaders[i]];
+      (void)hipSetDevice(a->device);
+      e = allreduce(a->d_table, a->d_table, words, kNcclUint64, kNcclSum, comms[i], a->stream);
     }
     int e2 = gend();
     if (!e) e = e2;
-    for (int i = 0; i < n; ++i) {
-      (void)hipSetDevice(accs[i]->device);
-      (void)hipStreamSynchronize(accs[i]->stream);
+    for (int i = 0; i < nl; ++i) {
+      (void)hipSetDevice(accs[leaders[i]]->device);
+      (void)hipStreamSynchronize(accs[leaders[i]]->stream);
     }
-    for (int i = 0; i < n; ++i) cdestroy(comms[i]);
+    for (int i = 0; i < nl; ++i) cdestroy(comms[i]);
     if (e) return fail(QK_ERCCL, "ncclAllReduce: %s", errstr(e));
   }
+  // 3) every accumulator ends up holding the global table
   for (int i = 0; i < n; ++i) {
+    if (leader[i] != i) {
+      int rc = set_device(accs[i]);
+      if (rc) return rc;
+      QK_HIP(hipMemcpy(accs[i]->d_table, accs[leader[i]]->d_table, words * 8, hipMemcpyDeviceToDevice));
+    }
     accs[i]->max_len = max_len;
     accs[i]->n_reads = total_reads;
   }

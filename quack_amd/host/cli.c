@@ -9,10 +9,31 @@
  * rc 139).  Here every input is accumulated first; on any failure a message
  * goes to stderr, nothing to stdout, and the exit code is 1.
  */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "quack_host.h"
+
+/* one read_fastq() (quack.c:911 / 917); the two mates of a pair are independent
+ * accumulations, so they run concurrently — printed forward first regardless */
+typedef struct {
+  const char *path;
+  const uint32_t *bitset;
+  const int *devs;
+  int n_devs;
+  qk_base_info *tab;
+  uint64_t max_len, n_reads;
+  int rc;
+  char err[512];
+} file_job;
+
+static void *file_job_main(void *arg) {
+  file_job *j = arg;
+  j->rc = qkh_accumulate_file(j->path, j->bitset, j->devs, j->n_devs, &j->tab, &j->max_len, &j->n_reads);
+  if (j->rc) snprintf(j->err, sizeof j->err, "%s", qkh_last_error());
+  return NULL;
+}
 
 static const char *const k_version = "quack 1.1.1";   /* quack.c:54 */
 
@@ -118,14 +139,35 @@ int qkh_main(int argc, char **argv) {
 
   /* accumulate first (quack.c:911,917), print afterwards */
   {
-    const char *files[2] = {paired ? o.forward : o.unpaired, paired ? o.reverse : NULL};
-    for (int k = 0; k < 2 && files[k]; k++) {
-      if (qkh_accumulate_file(files[k], bitset, devs, n_devs, &tab[k], &max_len[k], &n_reads[k])) {
-        fprintf(stderr, "quack: %s\n", qkh_last_error());
+    file_job jobs[2];
+    pthread_t th;
+    int n_jobs = paired ? 2 : 1, threaded = 0;
+    memset(jobs, 0, sizeof jobs);
+    jobs[0].path = paired ? o.forward : o.unpaired;
+    jobs[1].path = o.reverse;
+    for (int k = 0; k < n_jobs; k++) {
+      jobs[k].bitset = bitset;
+      jobs[k].devs = devs;
+      jobs[k].n_devs = n_devs;
+    }
+    if (paired && pthread_create(&th, NULL, file_job_main, &jobs[1]) == 0) threaded = 1;
+    file_job_main(&jobs[0]);
+    if (paired) {
+      if (threaded) pthread_join(th, NULL);
+      else file_job_main(&jobs[1]);
+    }
+    for (int k = 0; k < n_jobs; k++) {
+      tab[k] = jobs[k].tab;
+      max_len[k] = jobs[k].max_len;
+      n_reads[k] = jobs[k].n_reads;
+    }
+    for (int k = 0; k < n_jobs; k++) {
+      if (jobs[k].rc) {
+        fprintf(stderr, "quack: %s\n", jobs[k].err);
         goto done;
       }
       if (max_len[k] == 0) {
-        fprintf(stderr, "quack: %s: no sequence data\n", files[k]);
+        fprintf(stderr, "quack: %s: no sequence data\n", jobs[k].path);
         goto done;
       }
     }

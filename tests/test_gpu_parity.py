@@ -205,6 +205,39 @@ def test_read_fastq_mirror(fname, adapters):
     assert_same((sd.bases, sd.number_of_sequences), ob.read_fastq(cases.inp(fname), k))
 
 
+def test_sharded_accumulators_in_one_process():
+    """batches dealt round-robin to three accumulators (one device here), merged
+    by qk_accum_allreduce: equals one accumulator that saw every batch"""
+    from quack_amd import api
+    seq, qual, off = synth.ragged(30000, 1, 260, seed=61)
+    k = ob.kmers_from_seqs(synth.synthetic_adapters())
+    want = ob.accumulate_batch(seq, qual, off, kmers=k)
+    accs = [quack_amd.Accumulator(0, ob.kmers_to_bitset(k)) for _ in range(3)]
+    try:
+        n = len(off) - 1
+        cut = [n * i // 10 for i in range(11)]
+        for b, (a, e) in enumerate(zip(cut, cut[1:])):
+            lo, hi = int(off[a]), int(off[e])
+            accs[b % 3].submit(seq[lo:hi], qual[lo:hi], off[a:e + 1] - off[a])
+        api.allreduce(accs)
+        for acc in accs:                       # every shard now holds the global table
+            sd = acc.finish()
+            assert_same((sd.bases, sd.number_of_sequences), want)
+    finally:
+        for acc in accs:
+            acc.close()
+
+
+@pytest.mark.parametrize("name", ["ragged100_adapters", "paired_adapters_named", "long40", "uniform100"])
+def test_cli_sharded_over_three_accumulators(name):
+    """QUACK_DEVICES=0,0,0: the CLI's multi-device path on one GPU"""
+    argv = dict(cases.load())[name]
+    r = subprocess.run([QUACK] + argv, capture_output=True, cwd=cases.inp(""),
+                       env=dict(os.environ, QUACK_DEVICES="0,0,0", QUACK_HIP_BATCH_MB="1"))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == cases.golden_svg(name)
+
+
 def test_device_table_roundtrip_and_single_rank_allreduce():
     """export -> all-reduce (world of one, RCCL) -> import leaves the table intact"""
     import torch
