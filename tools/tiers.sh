@@ -1,24 +1,20 @@
 #!/bin/bash
-# Run ON THE GPU BOX: the three timing tiers of SURVEY §8d for config-2-shaped
-# input, plus bench lines for the other single-GPU configs.
+# Run ON THE GPU BOX: the timing tiers of SURVEY §8d for config-2-shaped input.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/tiers
-mkdir -p $OUT
 cd $ROOT
-echo "nproc $(nproc)"; lscpu | grep -E "Model name|^CPU\(s\)" 
+echo "nproc $(nproc)"; lscpu | grep -E "Model name" 
 echo "== (ii) H2D-inclusive (pinned double buffer)"
-timeout -k 10 200 ./tools/kbench 2000000 150 0 0 0 0 1 1 | grep -E "h2d|mode=0"
-QUACK_HIP_BATCH_MB=256 timeout -k 10 200 ./tools/kbench 4000000 150 0 0 0 0 1 1 | grep -E "h2d"
-echo "== (iii) end-to-end CLI, 4M x 150 bp"
+timeout -k 10 200 ./tools/kbench 2000000 150 0 0 12 0 1 1 | grep -E "h2d"
+echo "== (iii) end-to-end CLI, 4M x 150 bp (0.6 Gbases)"
 ./tools/gen_fastq /tmp/e2e.fq.gz 4000000 150 150 2
 ./tools/gen_fastq /tmp/e2e.fq 4000000 150 150 2
-ls -la /tmp/e2e.fq.gz /tmp/e2e.fq
+./tools/gen_fastq /tmp/e2e_R2.fq.gz 4000000 150 150 5 2 30
+ls -la /tmp/e2e.fq.gz /tmp/e2e.fq | awk '{print $5, $9}'
+TIMEFORMAT="%R s wall, %U s user"
 for f in /tmp/e2e.fq.gz /tmp/e2e.fq; do
-  for i in 1 2; do /usr/bin/time -f "$f wall %e s user %U s" ./quack_amd/host/quack -u $f > /tmp/e2e.svg; done
+  for i in 1 2; do echo -n "quack -u $f : "; { time ./quack_amd/host/quack -u $f > /tmp/e2e.svg; } 2>&1; done
 done
-/usr/bin/time -f "gzip -dc wall %e s" gzip -dc /tmp/e2e.fq.gz > /dev/null
-/usr/bin/time -f "oracle (CPU restatement) gz wall %e s" ./oracle/_build/quack_oracle time /tmp/e2e.fq.gz
-/usr/bin/time -f "oracle (CPU restatement) plain wall %e s" ./oracle/_build/quack_oracle time /tmp/e2e.fq
-echo "== bench cfg3 / cfg5"
-timeout -k 10 400 python bench.py --workload cfg3 > $OUT/bench_cfg3.json 2>/dev/null; cat $OUT/bench_cfg3.json
-timeout -k 10 400 python bench.py --workload cfg5 > $OUT/bench_cfg5.json 2>/dev/null; cat $OUT/bench_cfg5.json
+echo -n "quack -1 gz -2 gz (paired, 1.2 Gbases): "; { time ./quack_amd/host/quack -1 /tmp/e2e.fq.gz -2 /tmp/e2e_R2.fq.gz > /tmp/e2e.svg; } 2>&1
+echo -n "gzip -dc: "; { time gzip -dc /tmp/e2e.fq.gz > /dev/null; } 2>&1
+echo -n "oracle (CPU restatement) gz: "; { time ./oracle/_build/quack_oracle time /tmp/e2e.fq.gz; } 2>&1
+echo -n "oracle (CPU restatement) plain: "; { time ./oracle/_build/quack_oracle time /tmp/e2e.fq; } 2>&1
