@@ -64,7 +64,8 @@ struct HistParams {
   uint32_t ch;                  // chunks per tile = tile_pos / 8
   uint32_t row_dwords;          // LDS row stride: 4*ch rounded up to 32 banks
   uint32_t reads_per_iter;      // chunk lanes per workgroup / ch
-  uint32_t n_slices;            // read slices (grid = n_tiles * n_slices rounded to 8)
+  uint32_t n_slices;            // read slices per tile; work items = n_tiles * n_slices
+  uint32_t *queue;              // [n_tiles] slice counters (several tiles), or NULL
   uint32_t no_adapters;         // kmers == NULL semantics (quack.c:210,215)
   uint32_t filter_mask;         // bits in kmer_filter - 1
 };
@@ -119,33 +120,30 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 
 // MODE: 0 full; 1 loads only; 2 quality only; 3 bases only (ablation builds
 // used by tools/kbench only; the shim always launches MODE 0).
+//
+// Work items = (tile, read slice).  One tile: block b owns slice b.  Several
+// tiles (p.queue set): persistent workgroups pull slices from per-tile device
+// counters and only flush / clear their LDS histogram when they change tile (or
+// their u16 counters could overflow), so the number of table flushes is
+// ~ tiles + workgroups instead of tiles x slices.
 template <int T, int U, bool FIXED, int MODE, bool ADAPT = false>
 __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
   extern __shared__ uint32_t lds[];
   const uint32_t tid = threadIdx.x;
   const uint32_t CH = p.ch;
-  // blocks b and b+8 share an XCD (round-robin dispatch): give them the tiles
-  // of ONE read slice, so the cache lines two tiles share are fetched into one
-  // L2.  Purely a speed choice; any placement is correct.
-  const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
-  const uint32_t tile = k % p.n_tiles;
-  const uint32_t slice = (k / p.n_tiles) * 8u + xcd;
-  if (slice >= p.n_slices) return;
-  const uint32_t P0 = tile * p.tile_pos;
   const uint32_t RD = p.row_dwords;
   const uint32_t TP = 8u * CH;  // == p.tile_pos
   const uint32_t hist_words = kQRows * RD;
   uint32_t *lds_base = lds + hist_words;  // [4][TP]
   uint32_t *lds_len = lds_base + 4u * TP;
-  uint32_t *lds_misc = lds_len + TP;
-
+  uint32_t *lds_misc = lds_len + TP;      // [0] reads longer than 10, [1] next item
   uint32_t *lds_filter = lds_misc + 4u;   // ADAPT only
   const uint8_t *filt8 = reinterpret_cast<const uint8_t *>(lds_filter);
+  const uint64_t TL = p.table_len;
 
-  for (uint32_t i = tid; i < hist_words + 5u * TP + 4u; i += T) lds[i] = 0;
-  if (ADAPT)
+  if (ADAPT) {
     for (uint32_t i = tid; i < kFusedFilterWords; i += T) lds_filter[i] = p.kmer_filter[i];
-  __syncthreads();
+  }
 
   // ADAPT: lanes 0 and 1 of every wave are feeders: they recompute the chunks
   // of the previous wave's lanes 62/63 so that lanes 2/3 find their
@@ -158,37 +156,15 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
   const uint32_t ch = slot - ri * CH;
   const uint32_t RW = p.reads_per_iter;
   const bool lane_on = lane_id >= feeders && ri < RW;
-  const uint32_t cpos = P0 + 8u * ch;   // first position of the owned chunk
   const uint32_t row_bytes = 4u * RD;   // a multiple of 128 B: bank == column
   uint32_t qcol[4];
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) qcol[jj] = (jj * CH + ch) * 4u;
   const uint32_t one_lo = 1u, one_hi = 65536u;
 
-  const uint64_t r_begin = (uint64_t)slice * p.reads_per_slice;
-  uint64_t r_end = r_begin + p.reads_per_slice;
-  if (r_end > p.n_reads) r_end = p.n_reads;
-  const uint32_t slice_reads = r_end > r_begin ? (uint32_t)(r_end - r_begin) : 0u;
-  // reads past the slice are still addressable (idle lanes load too); this is
-  // how far the index may run before it leaves offsets[]
-  const uint64_t idx_room = p.n_reads > r_begin ? p.n_reads - r_begin : 0;
-  const uint32_t idx_limit = idx_room < 0xFFFFFFFFull ? (uint32_t)idx_room : 0xFFFFFFFFu;
-
-  // 32-bit byte offsets relative to a 4-byte-aligned, workgroup-uniform base
-  uint64_t slice_base = 0;
-  if (slice_reads) slice_base = FIXED ? r_begin * p.read_len : p.offsets[r_begin];
-  const uint64_t base_al = slice_base & ~3ull;
-  const uint8_t *qbase = p.qual + base_al;
-  const uint8_t *sbase = p.seq + base_al;
-  const uint64_t *obase = FIXED ? nullptr : p.offsets + r_begin;
-  const uint64_t room = p.total_bytes - base_al;   // total_bytes >= base_al when slice_reads > 0
-  const uint32_t off_limit = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
-  const uint32_t cposp = cpos + (uint32_t)(slice_base & 3ull);
-  // windows ending before position 9 do not exist
-  const uint32_t win_mask = cpos >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cpos)) - 1u));
-
-  uint32_t n_gt10 = 0;   // reads longer than 10 (kmers==NULL path, quack.c:215)
-  uint32_t keep = 0;     // MODE 1 only
+  uint32_t n_gt10 = 0;        // reads longer than 10 (kmers==NULL path, quack.c:215)
+  uint32_t fixed_reads = 0;   // FIXED, tile 0: reads seen since the last flush
+  uint32_t keep = 0;          // MODE 1 only
   // SWAR byte counters for the 8 owned positions: [0] positions 0-3, [1] 4-7
   uint32_t acc_v[2] = {0, 0}, acc_t[2] = {0, 0}, acc_c[2] = {0, 0}, acc_g[2] = {0, 0};
   uint32_t since_spill = 0;
@@ -214,229 +190,309 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
     since_spill = 0;
   };
 
-  // ragged batches: the start/end offsets of the NEXT iteration's reads are
-  // requested while the current iteration is processed, so the data loads never
-  // wait on an offsets round trip
-  uint64_t nx0[U], nx1[U];
-  auto fetch_offsets = [&](uint32_t it_next) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t rel = it_next + (uint32_t)u * RW + ri;
-      const uint32_t i0 = rel < idx_limit ? rel : idx_limit;
-      const uint32_t i1 = i0 < idx_limit ? i0 + 1u : idx_limit;
-      nx0[u] = obase[i0];
-      nx1[u] = obase[i1];
-    }
+  auto zero_lds = [&]() {
+    for (uint32_t i = tid; i < hist_words + 5u * TP + 1u; i += T) lds[i] = 0;
   };
-  if (!FIXED && slice_reads) fetch_offsets(0);
-
-  for (uint32_t it = 0; it < slice_reads; it += RW * U) {
-    u32x3 q[U], s[U];
-    uint32_t nv[U], sk[U];
-    uint64_t cur0[U], cur1[U];
-    if (!FIXED) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        cur0[u] = nx0[u];
-        cur1[u] = nx1[u];
-      }
-      if (it + RW * U < slice_reads) fetch_offsets(it + RW * U);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t rel = it + (uint32_t)u * RW + ri;   // read index within the slice
-      const bool ok = lane_on && rel < slice_reads;
-      uint32_t off, len;
-      if (FIXED) {
-        off = rel * p.read_len + cposp;
-        len = p.read_len;
-      } else {
-        len = (uint32_t)(cur1[u] - cur0[u]);
-        off = (uint32_t)(cur0[u] - base_al) + cpos;
-      }
-      // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
-      // compute codes like their originals but count nothing
-      uint32_t n_raw = (rel < slice_reads && ri < RW && len > cpos) ? len - cpos : 0u;
-      n_raw = n_raw > 8u ? 8u : n_raw;
-      nv[u] = lane_on ? n_raw : 0u;
-      off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
-      sk[u] = off & 3u;
-      off &= ~3u;
-      if (FIXED) {
-        q[u] = load12_aligned(qbase + off);
-        s[u] = load12_aligned(sbase + off);
-      } else {
-        // ragged: chunks past the end of their read fetch nothing (for 1-20 kb
-        // reads that is a third of all chunk slots)
-        q[u] = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        s[u] = q[u];
-        if (n_raw != 0) {
-          q[u] = load12_aligned(qbase + off);
-          s[u] = load12_aligned(sbase + off);
-        }
-      }
-      if (!FIXED) {
-        // length_count / kmers==NULL bookkeeping by the owner of chunk 0
-        if (ok && ch == 0 && tile == 0) {
-          n_gt10 += len > 10u ? 1u : 0u;
-          if (len != 0) {
-            const uint32_t lp = len - 1u;
-            if (lp < TP)
-              lds_add(lds_len, lp * 4u, 1u);
-            else
-              atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + lp], 1ull);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      // bytes past the end of the read -> 0xFF: quality row 127 is discarded
-      // at flush time, and 0xFF & 31 matches none of T/C/G.
-      const uint32_t n = nv[u];
-      // nothing of these reads reaches this tile (ragged batches, long reads):
-      // the whole wave moves on.  ADAPT needs every lane's codes, but then no
-      // lane has a valid window either.
-      if (!FIXED && __builtin_amdgcn_ballot_w64(n != 0) == 0) continue;
-      const uint2 qa = window8(q[u], sk[u]);
-      const uint2 sa = window8(s[u], sk[u]);
-      const uint32_t m0 = n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n));
-      const uint32_t m1 = n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu
-                                                   : (0xFFFFFFFFu << (8u * (n - 4u))));
-      const uint32_t mk[2] = {m0, m1};
-      const uint32_t qw[2] = {qa.x | m0, qa.y | m1};
-      const uint32_t sw[2] = {sa.x | m0, sa.y | m1};
-      if (MODE == 1) {
-        keep ^= qw[0] ^ qw[1] ^ sw[0] ^ sw[1];
-        continue;
-      }
-      if (MODE == 0 || MODE == 2) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t b = __builtin_amdgcn_ubfe(qw[j >> 2], 8 * (j & 3), 7);
-          lds_add(lds, __umul24(b, row_bytes) + qcol[j & 3], (j >> 2) ? one_hi : one_lo);
-        }
-      }
-      if (MODE == 0 || MODE == 3) {
-        // letter indicators come from the UNMASKED bytes when the adapter scan
-        // needs them (feeder lanes and chunk tails must still yield the real
-        // codes; window validity is enforced by `hits` masks below) and are
-        // masked per byte for the content counters
-        uint32_t et[2], ec[2], eg[2];
-        const uint32_t raw[2] = {sa.x, sa.y};
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const uint32_t valid01 = ~mk[d] & 0x01010101u;
-          const uint32_t src = ADAPT ? raw[d] : sw[d];
-          et[d] = swar_eq(src, kKeyT);
-          ec[d] = swar_eq(src, kKeyC);
-          eg[d] = swar_eq(src, kKeyG);
-          acc_v[d] += valid01;
-          acc_t[d] += ADAPT ? (et[d] & valid01) : et[d];
-          acc_c[d] += ADAPT ? (ec[d] & valid01) : ec[d];
-          acc_g[d] += ADAPT ? (eg[d] & valid01) : eg[d];
-        }
-        if (ADAPT) {
-          // 2-bit codes A0 T1 C2 G3 (quack.c:150) of the 8 owned bases, first
-          // base most significant: byte codes -> 8 bits per dword by multiply
-          uint32_t c8[2];
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const uint32_t cb = ((ec[d] + eg[d]) << 1) + (et[d] + eg[d]);
-            c8[d] = (cb * 0x40100401u) >> 24;
-          }
-          const uint32_t own16 = (c8[0] << 8) | c8[1];
-          const uint32_t prev16 = from_prev_lane(own16);   // positions cpos-8 .. cpos-1
-          const uint32_t prev2 = from_prev_lane(prev16);   // its low code: position cpos-9
-          const uint32_t plo = (prev16 << 16) | own16;
-          // window ending at owned position j = bits [2*(7-j), 2*(7-j)+20) of
-          // {prev2&3, plo}; the filter is keyed by the window's low 18 bits
-          uint32_t hits = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int sh = 2 * (7 - j);
-            const uint32_t byte = filt8[__builtin_amdgcn_ubfe(plo, sh + 3, kFusedFilterLog2 - 3)];
-            hits |= __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(plo, sh, 3), 1) << j;
-          }
-          // only windows that end inside the read, at e >= 9 (quack.c:206-213)
-          hits &= (1u << n) - 1u;
-          hits &= win_mask;
-          if (hits) {
-            uint32_t best = kNoHit;
-            while (hits) {
-              const int j = __builtin_ctz(hits);
-              hits &= hits - 1u;
-              const uint32_t km = (uint32_t)(((((uint64_t)(prev2 & 3u)) << 32) | plo) >> (2 * (7 - j))) & 0xFFFFFu;
-              if ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) {
-                best = cpos + (uint32_t)j;
-                break;
-              }
-            }
-            if (best != kNoHit)
-              atomicMin(&p.first_hit[r_begin + it + (uint32_t)u * RW + ri], best);
-          }
-        }
-      }
-    }
-    if (MODE == 0 || MODE == 3) {
-      since_spill += U;
-      if (since_spill + U > 255u) spill();   // byte counters hold <= 255
-    }
-  }
-  if (MODE == 0 || MODE == 3) spill();
-
-  if (MODE == 1) {
-    if (keep == 0x12345678u) lds[0] = keep;
-  }
-  if (!FIXED && n_gt10) lds_add(lds_misc, 0, n_gt10);
-  __syncthreads();
 
   // ---- flush: LDS -> planar u64 table; zero counters are skipped.  One wave
   // per quality row, lanes along positions (contiguous 512-B atomics).
-  const uint64_t TL = p.table_len;
-  const uint32_t wave = tid >> 6, lane = tid & 63u;
-  for (uint32_t row = 33u + wave; row <= 123u; row += T / 64) {  // quack.c:203: bin = byte - 33
-    for (uint32_t pp = lane; pp < TP; pp += 64u) {
-      const uint32_t c8 = pp >> 3, j = pp & 7u;
-      const uint32_t w = lds[row * RD + (j & 3u) * CH + c8];
-      const uint32_t c = (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
+  auto flush = [&](uint32_t tile) {
+    const uint32_t P0 = tile * p.tile_pos;
+    if (!FIXED && tile == 0 && n_gt10) {
+      lds_add(lds_misc, 0, n_gt10);
+      n_gt10 = 0;
+    }
+    __syncthreads();
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    for (uint32_t row = 33u + wave; row <= 123u; row += T / 64) {  // quack.c:203: bin = byte - 33
+      for (uint32_t pp = lane; pp < TP; pp += 64u) {
+        const uint32_t c8 = pp >> 3, j = pp & 7u;
+        const uint32_t w = lds[row * RD + (j & 3u) * CH + c8];
+        const uint32_t c = (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
+        const uint32_t pos = P0 + pp;
+        if (c != 0 && pos < p.table_len)
+          atomicAdd(&p.table[(uint64_t)(row - 33u) * TL + pos], (unsigned long long)c);
+      }
+    }
+    for (uint32_t pp = tid; pp < TP; pp += T) {
+      const uint32_t v = lds_base[pp];
       const uint32_t pos = P0 + pp;
-      if (c != 0 && pos < p.table_len)
-        atomicAdd(&p.table[(uint64_t)(row - 33u) * TL + pos], (unsigned long long)c);
+      if (v == 0 || pos >= p.table_len) continue;
+      const uint32_t t = lds_base[TP + pp], c = lds_base[2u * TP + pp], g = lds_base[3u * TP + pp];
+      unsigned long long *row0 = &p.table[(uint64_t)kRowContent * TL + pos];
+      const uint32_t a = v - t - c - g;                     // content[] order: A,T,C,G (quack.c:150)
+      if (a) atomicAdd(row0, (unsigned long long)a);
+      if (t) atomicAdd(row0 + TL, (unsigned long long)t);
+      if (c) atomicAdd(row0 + 2u * TL, (unsigned long long)c);
+      if (g) atomicAdd(row0 + 3u * TL, (unsigned long long)g);
+    }
+    if (tile == 0) {
+      if (FIXED) {
+        if (tid == 0 && fixed_reads != 0) {
+          const unsigned long long n = fixed_reads;
+          if (p.read_len != 0)
+            atomicAdd(&p.table[(uint64_t)kRowLength * TL + p.read_len - 1u], n);   // quack.c:219
+          if (p.no_adapters && p.read_len > 10u)
+            atomicAdd(&p.table[(uint64_t)kRowKmer * TL + 10u], n);                 // quack.c:215-217, i == 10
+        }
+      } else {
+        for (uint32_t pp = tid; pp < TP; pp += T) {
+          const uint32_t c = lds_len[pp];
+          if (c != 0 && pp < p.table_len)
+            atomicAdd(&p.table[(uint64_t)kRowLength * TL + pp], (unsigned long long)c);
+        }
+        if (tid == 0 && p.no_adapters && lds_misc[0] != 0)
+          atomicAdd(&p.table[(uint64_t)kRowKmer * TL + 10u], (unsigned long long)lds_misc[0]);
+      }
+    }
+    fixed_reads = 0;
+  };
+
+  // ---- one work item: reads [r_begin, r_end) x positions of `tile`
+  auto process = [&](uint32_t tile, uint32_t slice) {
+    const uint32_t P0 = tile * p.tile_pos;
+    const uint32_t cpos = P0 + 8u * ch;   // first position of the owned chunk
+    const uint64_t r_begin = (uint64_t)slice * p.reads_per_slice;
+    uint64_t r_end = r_begin + p.reads_per_slice;
+    if (r_end > p.n_reads) r_end = p.n_reads;
+    const uint32_t slice_reads = r_end > r_begin ? (uint32_t)(r_end - r_begin) : 0u;
+    if (FIXED && tile == 0) fixed_reads += slice_reads;
+    // reads past the slice are still addressable; this is how far the index
+    // may run before it leaves offsets[]
+    const uint64_t idx_room = p.n_reads > r_begin ? p.n_reads - r_begin : 0;
+    const uint32_t idx_limit = idx_room < 0xFFFFFFFFull ? (uint32_t)idx_room : 0xFFFFFFFFu;
+
+    // 32-bit byte offsets relative to a 4-byte-aligned, workgroup-uniform base
+    uint64_t slice_base = 0;
+    if (slice_reads) slice_base = FIXED ? r_begin * p.read_len : p.offsets[r_begin];
+    const uint64_t base_al = slice_base & ~3ull;
+    const uint8_t *qbase = p.qual + base_al;
+    const uint8_t *sbase = p.seq + base_al;
+    const uint64_t *obase = FIXED ? nullptr : p.offsets + r_begin;
+    const uint64_t room = p.total_bytes - base_al;   // total_bytes >= base_al when slice_reads > 0
+    const uint32_t off_limit = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
+    const uint32_t cposp = cpos + (uint32_t)(slice_base & 3ull);
+    // windows ending before position 9 do not exist
+    const uint32_t win_mask = cpos >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cpos)) - 1u));
+
+    // ragged batches: the start/end offsets of the NEXT iteration's reads are
+    // requested while the current iteration is processed, so the data loads
+    // never wait on an offsets round trip
+    uint64_t nx0[U], nx1[U];
+    auto fetch_offsets = [&](uint32_t it_next) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t rel = it_next + (uint32_t)u * RW + ri;
+        const uint32_t i0 = rel < idx_limit ? rel : idx_limit;
+        const uint32_t i1 = i0 < idx_limit ? i0 + 1u : idx_limit;
+        nx0[u] = obase[i0];
+        nx1[u] = obase[i1];
+      }
+    };
+    if (!FIXED && slice_reads) fetch_offsets(0);
+
+    for (uint32_t it = 0; it < slice_reads; it += RW * U) {
+      u32x3 q[U], s[U];
+      uint32_t nv[U], sk[U];
+      uint64_t cur0[U], cur1[U];
+      if (!FIXED) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          cur0[u] = nx0[u];
+          cur1[u] = nx1[u];
+        }
+        if (it + RW * U < slice_reads) fetch_offsets(it + RW * U);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t rel = it + (uint32_t)u * RW + ri;   // read index within the slice
+        const bool ok = lane_on && rel < slice_reads;
+        uint32_t off, len;
+        if (FIXED) {
+          off = rel * p.read_len + cposp;
+          len = p.read_len;
+        } else {
+          len = (uint32_t)(cur1[u] - cur0[u]);
+          off = (uint32_t)(cur0[u] - base_al) + cpos;
+        }
+        // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
+        // compute codes like their originals but count nothing
+        uint32_t n_raw = (rel < slice_reads && ri < RW && len > cpos) ? len - cpos : 0u;
+        n_raw = n_raw > 8u ? 8u : n_raw;
+        nv[u] = lane_on ? n_raw : 0u;
+        off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
+        sk[u] = off & 3u;
+        off &= ~3u;
+        if (FIXED) {
+          q[u] = load12_aligned(qbase + off);
+          s[u] = load12_aligned(sbase + off);
+        } else {
+          // ragged: chunks past the end of their read fetch nothing (for 1-20 kb
+          // reads that is a third of all chunk slots)
+          q[u] = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+          s[u] = q[u];
+          if (n_raw != 0) {
+            q[u] = load12_aligned(qbase + off);
+            s[u] = load12_aligned(sbase + off);
+          }
+          // length_count / kmers==NULL bookkeeping by the owner of chunk 0
+          if (ok && ch == 0 && tile == 0) {
+            n_gt10 += len > 10u ? 1u : 0u;
+            if (len != 0) {
+              const uint32_t lp = len - 1u;
+              if (lp < TP)
+                lds_add(lds_len, lp * 4u, 1u);
+              else
+                atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + lp], 1ull);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // bytes past the end of the read -> 0xFF: quality row 127 is discarded
+        // at flush time, and 0xFF & 31 matches none of T/C/G.
+        const uint32_t n = nv[u];
+        // nothing of these reads reaches this tile (ragged batches, long
+        // reads): the whole wave moves on.  ADAPT needs every lane's codes, but
+        // then no lane has a valid window either.
+        if (!FIXED && __builtin_amdgcn_ballot_w64(n != 0) == 0) continue;
+        const uint2 qa = window8(q[u], sk[u]);
+        const uint2 sa = window8(s[u], sk[u]);
+        const uint32_t m0 = n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n));
+        const uint32_t m1 = n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu
+                                                     : (0xFFFFFFFFu << (8u * (n - 4u))));
+        const uint32_t mk[2] = {m0, m1};
+        const uint32_t qw[2] = {qa.x | m0, qa.y | m1};
+        const uint32_t sw[2] = {sa.x | m0, sa.y | m1};
+        if (MODE == 1) {
+          keep ^= qw[0] ^ qw[1] ^ sw[0] ^ sw[1];
+          continue;
+        }
+        if (MODE == 0 || MODE == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t b = __builtin_amdgcn_ubfe(qw[j >> 2], 8 * (j & 3), 7);
+            lds_add(lds, __umul24(b, row_bytes) + qcol[j & 3], (j >> 2) ? one_hi : one_lo);
+          }
+        }
+        if (MODE == 0 || MODE == 3) {
+          // letter indicators come from the UNMASKED bytes when the adapter scan
+          // needs them (feeder lanes and chunk tails must still yield the real
+          // codes; window validity is enforced by `hits` masks below) and are
+          // masked per byte for the content counters
+          uint32_t et[2], ec[2], eg[2];
+          const uint32_t raw[2] = {sa.x, sa.y};
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const uint32_t valid01 = ~mk[d] & 0x01010101u;
+            const uint32_t src = ADAPT ? raw[d] : sw[d];
+            et[d] = swar_eq(src, kKeyT);
+            ec[d] = swar_eq(src, kKeyC);
+            eg[d] = swar_eq(src, kKeyG);
+            acc_v[d] += valid01;
+            acc_t[d] += ADAPT ? (et[d] & valid01) : et[d];
+            acc_c[d] += ADAPT ? (ec[d] & valid01) : ec[d];
+            acc_g[d] += ADAPT ? (eg[d] & valid01) : eg[d];
+          }
+          if (ADAPT) {
+            // 2-bit codes A0 T1 C2 G3 (quack.c:150) of the 8 owned bases, first
+            // base most significant: byte codes -> 8 bits per dword by multiply
+            uint32_t c8[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const uint32_t cb = ((ec[d] + eg[d]) << 1) + (et[d] + eg[d]);
+              c8[d] = (cb * 0x40100401u) >> 24;
+            }
+            const uint32_t own16 = (c8[0] << 8) | c8[1];
+            const uint32_t prev16 = from_prev_lane(own16);   // positions cpos-8 .. cpos-1
+            const uint32_t prev2 = from_prev_lane(prev16);   // its low code: position cpos-9
+            const uint32_t plo = (prev16 << 16) | own16;
+            // window ending at owned position j = bits [2*(7-j), 2*(7-j)+20) of
+            // {prev2&3, plo}; the filter is keyed by the window's low 18 bits
+            uint32_t hits = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int sh = 2 * (7 - j);
+              const uint32_t byte = filt8[__builtin_amdgcn_ubfe(plo, sh + 3, kFusedFilterLog2 - 3)];
+              hits |= __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(plo, sh, 3), 1) << j;
+            }
+            // only windows that end inside the read, at e >= 9 (quack.c:206-213)
+            hits &= (1u << n) - 1u;
+            hits &= win_mask;
+            if (hits) {
+              uint32_t best = kNoHit;
+              while (hits) {
+                const int j = __builtin_ctz(hits);
+                hits &= hits - 1u;
+                const uint32_t km = (uint32_t)(((((uint64_t)(prev2 & 3u)) << 32) | plo) >> (2 * (7 - j))) & 0xFFFFFu;
+                if ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) {
+                  best = cpos + (uint32_t)j;
+                  break;
+                }
+              }
+              if (best != kNoHit)
+                atomicMin(&p.first_hit[r_begin + it + (uint32_t)u * RW + ri], best);
+            }
+          }
+        }
+      }
+      if (MODE == 0 || MODE == 3) {
+        since_spill += U;
+        if (since_spill + U > 255u) spill();   // byte counters hold <= 255
+      }
+    }
+    if (MODE == 0 || MODE == 3) spill();
+    return slice_reads;
+  };
+
+  // ---- work loop
+  uint32_t cur_tile = 0xFFFFFFFFu, reads_in_tile = 0;
+  auto run_item = [&](uint32_t tile, uint32_t slice) {
+    const uint64_t rb = (uint64_t)slice * p.reads_per_slice;
+    const uint64_t re = rb + p.reads_per_slice < p.n_reads ? rb + p.reads_per_slice : p.n_reads;
+    const uint32_t upcoming = re > rb ? (uint32_t)(re - rb) : 0u;
+    if (tile != cur_tile || reads_in_tile + upcoming > kMaxReadsPerSlice) {
+      if (cur_tile != 0xFFFFFFFFu) {
+        flush(cur_tile);
+        __syncthreads();
+      }
+      zero_lds();
+      __syncthreads();
+      cur_tile = tile;
+      reads_in_tile = 0;
+    }
+    reads_in_tile += process(tile, slice);
+  };
+  if (p.queue == nullptr) {
+    // one tile: block b owns read slice b
+    if (blockIdx.x < p.n_slices) run_item(0, blockIdx.x);
+  } else {
+    // several tiles: one queue of read slices per tile.  The workgroups start
+    // spread over all tiles (so that a read's tiles are consumed at about the
+    // same time by neighbouring workgroups, and flushes hit different table
+    // regions) and keep pulling slices of their tile; when it runs dry they
+    // move on to the next tile that still has work, flushing only then.
+    uint32_t tile = (uint32_t)(((uint64_t)blockIdx.x * p.n_tiles) / gridDim.x);
+    uint32_t dry = 0;
+    while (dry < p.n_tiles) {
+      __syncthreads();   // everybody has consumed lds_misc[1] of the previous round
+      if (tid == 0) lds_misc[1] = atomicAdd(&p.queue[tile], 1u);
+      __syncthreads();
+      const uint32_t slice = lds_misc[1];
+      if (slice >= p.n_slices) {
+        tile = tile + 1u == p.n_tiles ? 0u : tile + 1u;
+        ++dry;
+        continue;
+      }
+      dry = 0;
+      run_item(tile, slice);
     }
   }
-  for (uint32_t pp = tid; pp < TP; pp += T) {
-    const uint32_t v = lds_base[pp];
-    const uint32_t pos = P0 + pp;
-    if (v == 0 || pos >= p.table_len) continue;
-    const uint32_t t = lds_base[TP + pp], c = lds_base[2u * TP + pp], g = lds_base[3u * TP + pp];
-    unsigned long long *row0 = &p.table[(uint64_t)kRowContent * TL + pos];
-    const uint32_t a = v - t - c - g;                     // content[] order: A,T,C,G (quack.c:150)
-    if (a) atomicAdd(row0, (unsigned long long)a);
-    if (t) atomicAdd(row0 + TL, (unsigned long long)t);
-    if (c) atomicAdd(row0 + 2u * TL, (unsigned long long)c);
-    if (g) atomicAdd(row0 + 3u * TL, (unsigned long long)g);
+  if (MODE == 1) {
+    if (keep == 0x12345678u) lds[0] = keep;
   }
-  if (tile == 0) {
-    if (FIXED) {
-      if (tid == 0 && r_end > r_begin) {
-        const unsigned long long n = r_end - r_begin;
-        if (p.read_len != 0)
-          atomicAdd(&p.table[(uint64_t)kRowLength * TL + p.read_len - 1u], n);   // quack.c:219
-        if (p.no_adapters && p.read_len > 10u)
-          atomicAdd(&p.table[(uint64_t)kRowKmer * TL + 10u], n);                 // quack.c:215-217, i == 10
-      }
-    } else {
-      for (uint32_t pp = tid; pp < TP; pp += T) {
-        const uint32_t c = lds_len[pp];
-        if (c != 0 && pp < p.table_len)
-          atomicAdd(&p.table[(uint64_t)kRowLength * TL + pp], (unsigned long long)c);
-      }
-      if (tid == 0 && p.no_adapters && lds_misc[0] != 0)
-        atomicAdd(&p.table[(uint64_t)kRowKmer * TL + 10u],
-                  (unsigned long long)lds_misc[0]);
-    }
-  }
+  if (cur_tile != 0xFFFFFFFFu) flush(cur_tile);
 }
 
 // dst += src over the planar tables of two accumulators on the same device

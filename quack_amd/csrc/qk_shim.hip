@@ -86,6 +86,8 @@ struct qk_accum {
   uint64_t cap_bytes = 0, cap_reads = 0;
   hipStream_t stream = nullptr;     // own stream for device-resident submits
   bool foreign_stream_used = false;
+  uint32_t *d_queues = nullptr;       // ring of work-queue counters (multi-tile launches)
+  unsigned queue_seq = 0;
   uint32_t *d_hit_scratch = nullptr;  // first-hit buffer for device submits
   uint64_t hit_scratch_reads = 0;
   // tuning
@@ -124,10 +126,12 @@ int ensure_slots(qk_accum *a) {
 
 // Grow the planar table so that it holds `need` positions.  Rare (once or
 // twice per file, like the realloc at quack.c:194-198), so it synchronises.
-int grow_table(qk_accum *a, uint64_t need) {
+int grow_table(qk_accum *a, uint64_t need, bool exact = false) {
   if (need <= a->table_len) return QK_OK;
   QK_HIP(hipDeviceSynchronize());
-  uint64_t nl = std::max<uint64_t>(need, a->table_len * 2);
+  // amortised doubling while reads arrive; `exact` when several accumulators
+  // must agree on one geometry before their tables are summed
+  uint64_t nl = exact ? need : std::max<uint64_t>(need, a->table_len * 2);
   nl = round_up(std::max<uint64_t>(nl, 64), 64);
   unsigned long long *nt = nullptr;
   const size_t words = (size_t)QK_N_ROWS * nl + 1;
@@ -145,9 +149,11 @@ int grow_table(qk_accum *a, uint64_t need) {
 
 struct Plan {
   uint32_t n_tiles, tile_pos, ch, rw;
-  uint64_t reads_per_slice, n_slices;
-  bool fused_adapters;
+  uint64_t reads_per_slice, n_slices, n_blocks;
+  bool fused_adapters, dynamic;
 };
+constexpr unsigned kQueueRing = 16;      // launches that may be in flight
+constexpr unsigned kQueueTiles = 8192;  // counters per launch
 
 // Launch geometry.  One position tile whenever the LDS histogram of the whole
 // read fits (<= 576 positions, 448 with the adapter filter resident): tiles of
@@ -185,15 +191,18 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, Plan *pl) {
   // threads per CU, and the LDS image must fit as many times
   uint32_t wgs = a->wgs_per_cu > 0 ? (uint32_t)a->wgs_per_cu
                                    : std::max<uint32_t>(1, std::min<uint32_t>(1024 / T, (uint32_t)(160 * 1024 / lds)));
-  // single tile: one resident wave of workgroups.  Several tiles: reads do not
-  // reach the far tiles equally, so over-decompose 4x and let the dispatcher
-  // balance (slices in multiples of 8, one per XCD).
-  uint64_t target = (uint64_t)a->n_cu * wgs * (n_tiles > 1 ? 4 : 1);
-  uint64_t n_slices = std::max<uint64_t>(1, target / n_tiles);
-  if (n_tiles > 1) n_slices = round_up(n_slices, 8);
+  // Work items = tiles x read slices.  Single tile: one item per resident
+  // workgroup.  Several tiles (long reads): reads do not reach the far tiles
+  // equally, so the slices are cut ~16x finer than the resident workgroups and
+  // pulled from a device queue in tile-major order; a workgroup flushes its LDS
+  // histogram only when its tile changes.
+  const uint64_t resident = (uint64_t)a->n_cu * wgs;
+  pl->dynamic = n_tiles > 1;
+  uint64_t want_items = pl->dynamic ? resident * 16 : resident;
+  uint64_t n_slices = std::max<uint64_t>(1, want_items / n_tiles);
   uint64_t rps = (n_reads + n_slices - 1) / n_slices;
   rps = round_up(std::max<uint64_t>(rps, 1), step);
-  // u16 LDS counters: a workgroup may see at most 65535 reads
+  // u16 LDS counters: a workgroup may see at most 65535 reads between flushes
   if (step * 2 > qk::kMaxReadsPerSlice) return fail(QK_EINVAL, "tile too wide for u16 counters");
   uint64_t rcap = (qk::kMaxReadsPerSlice - step) / step * step;
   // the kernel addresses a slice with 32-bit byte offsets
@@ -203,6 +212,8 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, Plan *pl) {
   if (rps > rcap) rps = rcap;
   pl->reads_per_slice = rps;
   pl->n_slices = (n_reads + rps - 1) / rps;
+  if (pl->n_slices > 0xFFFFFF00ull) return fail(QK_EINVAL, "too many read slices");
+  pl->n_blocks = pl->dynamic ? std::max<uint64_t>(resident, n_tiles <= resident ? resident : resident) : pl->n_slices;
   return QK_OK;
 }
 
@@ -291,6 +302,12 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.ch = pl.ch;
   hp.reads_per_iter = pl.rw;
   hp.n_slices = (uint32_t)pl.n_slices;
+  hp.queue = nullptr;
+  if (pl.dynamic) {
+    if (pl.n_tiles > kQueueTiles) return fail(QK_EINVAL, "reads of %u bytes need more position tiles than supported", max_len);
+    hp.queue = a->d_queues + (size_t)(a->queue_seq++ % kQueueRing) * kQueueTiles;
+    QK_HIP(hipMemsetAsync(hp.queue, 0, pl.n_tiles * sizeof(uint32_t), st));
+  }
   hp.row_dwords = qk::hist_row_dwords(pl.ch);
   hp.no_adapters = a->adapters ? 0 : 1;
 
@@ -302,8 +319,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     QK_HIP(hipEventRecord(tl.t0, st));
   }
   if (pl.fused_adapters) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
-  rc = launch_hist(a, hp, d_off == nullptr, g_ablation_mode, pl.fused_adapters,
-                   round_up(pl.n_slices, 8) * pl.n_tiles, st);
+  rc = launch_hist(a, hp, d_off == nullptr, g_ablation_mode, pl.fused_adapters, pl.n_blocks, st);
   if (rc) return rc;
   if (a->timing) {
     QK_HIP(hipEventRecord(tl.t1, st));
@@ -398,6 +414,10 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
         break;
       }
     }
+    if (hipMalloc((void **)&a->d_queues, (size_t)kQueueRing * kQueueTiles * sizeof(uint32_t)) != hipSuccess) {
+      rc = fail(QK_EHIP, "hipMalloc failed");
+      break;
+    }
     if ((rc = grow_table(a, std::max<uint64_t>(max_len_hint, 64)))) break;
   } while (0);
   if (rc) {
@@ -429,6 +449,7 @@ void qk_accum_destroy(qk_accum *a) {
     (void)hipEventDestroy(tl.t1);
   }
   for (auto e : a->event_pool) (void)hipEventDestroy(e);
+  if (a->d_queues) (void)hipFree(a->d_queues);
   if (a->d_hit_scratch) (void)hipFree(a->d_hit_scratch);
   if (a->d_kmer_bits) (void)hipFree(a->d_kmer_bits);
   if (a->d_kmer_filter) (void)hipFree(a->d_kmer_filter);
@@ -619,7 +640,7 @@ int qk_accum_reserve(qk_accum *a, uint64_t max_len) {
   if (!a) return fail(QK_EINVAL, "acc is NULL");
   int rc = set_device(a);
   if (rc) return rc;
-  return grow_table(a, max_len);
+  return grow_table(a, max_len, /*exact=*/true);
 }
 
 int qk_accum_export_table(qk_accum *a, void *d_dst, void *hip_stream) {
@@ -676,7 +697,7 @@ int qk_accum_allreduce(qk_accum **accs, int n) {
   for (int i = 0; i < n; ++i) {
     int rc = set_device(accs[i]);
     if (rc) return rc;
-    if ((rc = grow_table(accs[i], table_len))) return rc;
+    if ((rc = grow_table(accs[i], table_len, /*exact=*/true))) return rc;
     if (accs[i]->table_len != table_len) return fail(QK_ESTATE, "table sizes diverged");
   }
   const size_t words = (size_t)QK_N_ROWS * table_len;

@@ -32,20 +32,32 @@ def allreduce_planar(planar, table_len, group=None):
     return planar, common
 
 
-def allreduce_accumulator(acc, group=None):
-    """Sum this rank's qk_accum with every other rank's, in place (GPU path)."""
+def allreduce_accumulator(acc, group=None, via_host=False):
+    """Sum this rank's qk_accum with every other rank's, in place (GPU path).
+    via_host=True stages the table through host memory for backends without
+    device collectives (gloo; used to rehearse the N>1 path on a one-GPU box)."""
     max_len, _ = acc.stats()
-    ml = torch.tensor([max_len], dtype=torch.int64, device="cuda:%d" % acc.device)
+    gpu = torch.device("cuda", acc.device)
+    coll = torch.device("cpu") if via_host else gpu
+    ml = torch.tensor([max_len], dtype=torch.int64, device=coll)
     dist.all_reduce(ml, op=dist.ReduceOp.MAX, group=group)
     # common geometry first, so that every rank exports the same number of words
-    words = torch.tensor([acc.table_words()], dtype=torch.int64, device=ml.device)
+    words = torch.tensor([acc.table_words()], dtype=torch.int64, device=coll)
     dist.all_reduce(words, op=dist.ReduceOp.MAX, group=group)
     table_len = (int(words.item()) - 1) // QK_N_ROWS
     acc.reserve(table_len)
     assert acc.table_words() == QK_N_ROWS * table_len + 1
-    buf = torch.empty(acc.table_words(), dtype=torch.int64, device=ml.device)
-    acc.export_table(buf)
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    buf = torch.empty(acc.table_words(), dtype=torch.int64, device=gpu)
+    torch.cuda.current_stream(gpu).synchronize()   # buf is allocated before the shim's stream writes it
+    acc.export_table(buf)                          # synchronises the shim's stream before returning
+    if via_host:
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        buf.copy_(host)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    # a finished NCCL call only orders torch's stream; the shim imports on its own stream
+    torch.cuda.current_stream(gpu).synchronize()
     acc.import_table(buf, int(ml.item()))
     return acc
 

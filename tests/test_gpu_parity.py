@@ -228,6 +228,47 @@ def test_sharded_accumulators_in_one_process():
             acc.close()
 
 
+def test_shards_with_different_longest_reads():
+    """shards whose tables grew to different lengths (one saw only short
+    reads, one a 3 kb read after doubling a few times) must agree on one geometry"""
+    import torch
+    from quack_amd import api, distributed as qd
+    parts = [synth.ragged(4000, 1, 40, seed=71), synth.ragged(300, 100, 3000, seed=72),
+             synth.ragged(2000, 150, 150, seed=73)]
+    accs = [quack_amd.Accumulator(0, None, max_len_hint=8) for _ in parts]
+    try:
+        for acc, (s, q, o) in zip(accs, parts):
+            acc.submit(s[:int(o[len(o) // 2])], q[:int(o[len(o) // 2])], o[:len(o) // 2 + 1])   # grow in two steps
+            h = len(o) // 2
+            acc.submit(s[int(o[h]):], q[int(o[h]):], o[h:] - o[h])
+        assert len({a.table_words() for a in accs}) > 1
+        # the torch.distributed path's per-rank steps, on one device
+        words = max(a.table_words() for a in accs)
+        tl = (words - 1) // 97
+        bufs = []
+        for a in accs:
+            a.reserve(tl)
+            assert a.table_words() == words
+            b = torch.empty(words, dtype=torch.int64, device="cuda:0")
+            a.export_table(b)
+            bufs.append(b)
+        total = sum(bufs)
+        api.allreduce(accs)                      # in-process path
+        seq = np.concatenate([p[0] for p in parts])
+        qual = np.concatenate([p[1] for p in parts])
+        lens = np.concatenate([np.diff(p[2].astype(np.int64)) for p in parts])
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        want = ob.accumulate_batch(seq, qual, off)
+        sd = accs[0].finish()
+        assert_same((sd.bases, sd.number_of_sequences), want)
+        got, n_all = qd.bases_from_planar(total.cpu(), tl, want[0].shape[0])
+        assert n_all == want[1]
+        np.testing.assert_array_equal(got, want[0])
+    finally:
+        for a in accs:
+            a.close()
+
+
 @pytest.mark.parametrize("name", ["ragged100_adapters", "paired_adapters_named", "long40", "uniform100"])
 def test_cli_sharded_over_three_accumulators(name):
     """QUACK_DEVICES=0,0,0: the CLI's multi-device path on one GPU"""
