@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "qk_kernels.hip.h"
 
 namespace qk {
@@ -156,6 +158,50 @@ inline int launch_adapter_scan(const HistParams &hp, int n_cu, hipStream_t st) {
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return launch_adapter_count(hp, n_cu, st);
+}
+
+// Build the LDS-resident exact table of the fused path: 2^log2b buckets of
+// eight u16 slots, keyed by km*mul mod 2^20.  Returns false when no (mul, size)
+// up to `max_log2` avoids a bucket overflow (very large adapter sets): the
+// kernel then falls back to the global bitset for filter hits.
+inline bool build_kmer_buckets(const uint32_t *host_bits, uint32_t max_log2, std::vector<uint16_t> *out,
+                               uint32_t *log2b_out, uint32_t *mul_out) {
+  std::vector<uint32_t> kms;
+  for (uint32_t w = 0; w < (1u << 15); ++w) {
+    uint32_t v = host_bits[w];
+    while (v) {
+      kms.push_back(w * 32u + (uint32_t)__builtin_ctz(v));
+      v &= v - 1;
+    }
+  }
+  uint32_t log2b = 6;
+  while (log2b < max_log2 && (8u << log2b) < kms.size() * 3) ++log2b;   // ~1/3 full to start with
+  uint64_t seed = 0x9E3779B97F4A7C15ull;
+  for (; log2b <= max_log2; ++log2b) {
+    for (int attempt = 0; attempt < 32; ++attempt) {
+      seed = seed * 6364136223846793005ull + 1442695040888963407ull;
+      const uint32_t mul = ((uint32_t)(seed >> 33) & 0xFFFFFu) | 1u;
+      std::vector<uint16_t> tab((size_t)8 << log2b, 0);
+      std::vector<uint8_t> fill((size_t)1 << log2b, 0);
+      bool ok = true;
+      for (uint32_t km : kms) {
+        const uint32_t h = (km * mul) & 0xFFFFFu;
+        const uint32_t b = h >> (20 - log2b);
+        if (fill[b] == 8) {
+          ok = false;
+          break;
+        }
+        tab[(size_t)b * 8 + fill[b]++] = (uint16_t)((h & ((1u << (20 - log2b)) - 1u)) | 0x8000u);
+      }
+      if (ok) {
+        *out = tab;
+        *log2b_out = log2b;
+        *mul_out = mul;
+        return true;
+      }
+    }
+  }
+  return false;
 }
 
 // Upload the exact bitset and derive the LDS pre-filter from it.

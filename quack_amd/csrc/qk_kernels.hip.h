@@ -68,6 +68,11 @@ struct HistParams {
   uint32_t *queue;              // [n_tiles] slice counters (several tiles), or NULL
   uint32_t no_adapters;         // kmers == NULL semantics (quack.c:210,215)
   uint32_t filter_mask;         // bits in kmer_filter - 1
+  // exact LDS-resident membership table for the fused adapter path (0: use the
+  // global bitset): 2^bucket_log2 buckets of eight u16 remainders
+  const uint4 *kmer_buckets;
+  uint32_t bucket_log2;
+  uint32_t bucket_mul;          // odd multiplier: km' = km * mul mod 2^20 is a bijection
 };
 
 // 12 bytes from a 4-byte-aligned address: one global_load_dwordx3
@@ -109,8 +114,23 @@ inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch) { return (4u * 
 constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit window filter = 32 KiB of LDS
 constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
-inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false) {
-  return ((size_t)kQRows * hist_row_dwords(ch) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords : 0u)) * sizeof(uint32_t);
+inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false, uint32_t bucket_log2 = 0) {
+  return ((size_t)kQRows * hist_row_dwords(ch) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords : 0u)) * sizeof(uint32_t) +
+         (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0);
+}
+
+// Exact membership in the bucket table: km' = km*mul mod 2^20 (a bijection for
+// odd mul); the top bucket_log2 bits pick a 16-byte bucket, the rest (< 2^15)
+// is stored with bit 15 set.  Empty slots are 0.
+__device__ __forceinline__ bool bucket_has(const uint4 *buckets, uint32_t km, uint32_t mul, uint32_t log2b) {
+  const uint32_t h = (km * mul) & 0xFFFFFu;
+  const uint32_t rem = (h & ((1u << (20u - log2b)) - 1u)) | 0x8000u;
+  const uint4 b = buckets[h >> (20u - log2b)];
+  const uint32_t r2 = rem | (rem << 16);
+  const uint32_t x0 = b.x ^ r2, x1 = b.y ^ r2, x2 = b.z ^ r2, x3 = b.w ^ r2;
+  // a 16-bit half of x is zero <=> match
+  auto zero_half = [](uint32_t x) { return ((x & 0xFFFFu) == 0u) | ((x >> 16) == 0u); };
+  return zero_half(x0) | zero_half(x1) | zero_half(x2) | zero_half(x3);
 }
 
 // value of the same register in lane-1 (v_mov_b32_dpp wave_shr:1); lane 0 gets 0
@@ -139,10 +159,14 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
   uint32_t *lds_misc = lds_len + TP;      // [0] reads longer than 10, [1] next item
   uint32_t *lds_filter = lds_misc + 4u;   // ADAPT only
   const uint8_t *filt8 = reinterpret_cast<const uint8_t *>(lds_filter);
+  // (hist words, 5*TP, 4 and the filter are all multiples of 4 dwords: 16-byte aligned)
+  uint4 *lds_buckets = reinterpret_cast<uint4 *>(lds_filter + kFusedFilterWords);
   const uint64_t TL = p.table_len;
 
   if (ADAPT) {
     for (uint32_t i = tid; i < kFusedFilterWords; i += T) lds_filter[i] = p.kmer_filter[i];
+    if (p.bucket_log2)
+      for (uint32_t i = tid; i < (1u << p.bucket_log2); i += T) lds_buckets[i] = p.kmer_buckets[i];
   }
 
   // ADAPT: lanes 0 and 1 of every wave are feeders: they recompute the chunks
@@ -426,7 +450,9 @@ __global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
                 const int j = __builtin_ctz(hits);
                 hits &= hits - 1u;
                 const uint32_t km = (uint32_t)(((((uint64_t)(prev2 & 3u)) << 32) | plo) >> (2 * (7 - j))) & 0xFFFFFu;
-                if ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) {
+                const bool in_table = p.bucket_log2 ? bucket_has(lds_buckets, km, p.bucket_mul, p.bucket_log2)
+                                                    : ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) != 0;
+                if (in_table) {
                   best = cpos + (uint32_t)j;
                   break;
                 }

@@ -79,6 +79,8 @@ struct qk_accum {
   uint32_t *d_kmer_bits = nullptr;
   uint32_t *d_kmer_filter = nullptr;
   uint32_t filter_bits = 0;
+  uint4 *d_kmer_buckets = nullptr;    // exact LDS table of the fused path (may be absent)
+  uint32_t bucket_log2 = 0, bucket_mul = 0;
   // pipeline
   Slot slot[2];
   int next_slot = 0;
@@ -150,6 +152,7 @@ int grow_table(qk_accum *a, uint64_t need, bool exact = false) {
 struct Plan {
   uint32_t n_tiles, tile_pos, ch, rw;
   uint64_t reads_per_slice, n_slices, n_blocks;
+  uint32_t bucket_log2;
   bool fused_adapters, dynamic;
 };
 constexpr unsigned kQueueRing = 16;      // launches that may be in flight
@@ -185,7 +188,9 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, Plan *pl) {
   pl->ch = tile_pos / 8;
   pl->rw = (pl->fused_adapters ? T / 64 * 62 : T) / pl->ch;
   const uint64_t step = (uint64_t)pl->rw * U;
-  const size_t lds = qk::hist_lds_bytes(pl->ch, pl->fused_adapters);
+  pl->bucket_log2 = pl->fused_adapters ? a->bucket_log2 : 0;
+  if (pl->bucket_log2 && qk::hist_lds_bytes(pl->ch, true, pl->bucket_log2) > 160 * 1024) pl->bucket_log2 = 0;
+  const size_t lds = qk::hist_lds_bytes(pl->ch, pl->fused_adapters, pl->bucket_log2);
   if (lds > 160 * 1024) return fail(QK_EINVAL, "LDS tile too large (%zu bytes)", lds);
   // residency: the kernels need 89-104 VGPRs, i.e. 4 waves per SIMD = 1024
   // threads per CU, and the LDS image must fit as many times
@@ -244,7 +249,7 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, d
 
 int launch_hist(qk_accum *a, const qk::HistParams &hp, bool fixed, int mode, bool adapt,
                 uint64_t n_blocks, hipStream_t st) {
-  const size_t lds = qk::hist_lds_bytes(hp.ch, adapt);
+  const size_t lds = qk::hist_lds_bytes(hp.ch, adapt, hp.bucket_log2);
   dim3 grid((unsigned)n_blocks);
 #define QK_TU(TT, UU) \
   if (a->threads == TT && a->unroll == UU) return launch_hist_tu<TT, UU>(hp, fixed, mode, adapt, grid, lds, st);
@@ -292,6 +297,9 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.kmer_bits = a->d_kmer_bits;
   hp.kmer_filter = a->d_kmer_filter;
   hp.filter_mask = a->filter_bits ? a->filter_bits - 1 : 0;
+  hp.kmer_buckets = a->d_kmer_buckets;
+  hp.bucket_log2 = pl.bucket_log2;
+  hp.bucket_mul = a->bucket_mul;
   hp.n_reads = n_reads;
   hp.total_bytes = total_bytes;
   hp.reads_per_slice = pl.reads_per_slice;
@@ -413,6 +421,16 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
         rc = fail(QK_EHIP, "uploading adapter tables failed: %s", hipGetErrorString((hipError_t)rc));
         break;
       }
+      std::vector<uint16_t> buckets;
+      if (qk::build_kmer_buckets(kmer_bitset, /*max_log2=*/10, &buckets, &a->bucket_log2, &a->bucket_mul)) {
+        if (hipMalloc((void **)&a->d_kmer_buckets, buckets.size() * 2) != hipSuccess ||
+            hipMemcpy(a->d_kmer_buckets, buckets.data(), buckets.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+          rc = fail(QK_EHIP, "uploading adapter buckets failed");
+          break;
+        }
+      } else {
+        a->bucket_log2 = 0;   // huge adapter set: filter hits consult the global bitset
+      }
     }
     if (hipMalloc((void **)&a->d_queues, (size_t)kQueueRing * kQueueTiles * sizeof(uint32_t)) != hipSuccess) {
       rc = fail(QK_EHIP, "hipMalloc failed");
@@ -453,6 +471,7 @@ void qk_accum_destroy(qk_accum *a) {
   if (a->d_hit_scratch) (void)hipFree(a->d_hit_scratch);
   if (a->d_kmer_bits) (void)hipFree(a->d_kmer_bits);
   if (a->d_kmer_filter) (void)hipFree(a->d_kmer_filter);
+  if (a->d_kmer_buckets) (void)hipFree(a->d_kmer_buckets);
   if (a->d_table) (void)hipFree(a->d_table);
   if (a->stream) (void)hipStreamDestroy(a->stream);
   delete a;
