@@ -1,0 +1,122 @@
+"""Host feed: quack_amd/host/inflate_fast.c must decode exactly what zlib
+decodes — every block type, strategy, window size, multi-member files, and any
+output chunking (matches cut by the end of an output block)."""
+import ctypes
+import gzip
+import io
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from quack_amd import _capi
+import cases
+from test_reader_differential import product_tokenize
+
+L = _capi.host()
+L.qkh_inflate_read.restype = ctypes.c_long
+L.qkh_inflate_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+L.qkh_inflate_init.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+
+
+def inflate(comp, expect_len, chunk):
+    z = ctypes.create_string_buffer(1 << 18)          # > sizeof(qkh_inflate)
+    cbuf = ctypes.create_string_buffer(comp, len(comp))
+    L.qkh_inflate_init(z, cbuf, len(comp))
+    cap = expect_len + 70000
+    out = ctypes.create_string_buffer(cap)
+    base, pos, n = ctypes.addressof(out), 0, 0
+    while True:
+        n = L.qkh_inflate_read(z, base + pos, min(chunk, cap - pos), min(pos, 32768))
+        if n <= 0:
+            break
+        pos += n
+    return out.raw[:pos], n
+
+
+def gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=31, memlevel=8):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+    return c.compress(data) + c.flush()
+
+
+rng = random.Random(1)
+
+
+def fastq(n, length):
+    out = []
+    for i in range(n):
+        s = "".join(rng.choice("ACGT") for _ in range(length))
+        q = "".join(chr(33 + rng.randint(2, 41)) for _ in range(length))
+        out.append("@r%d\n%s\n+\n%s\n" % (i, s, q))
+    return "".join(out).encode()
+
+
+DATA = {
+    "empty": b"", "one": b"A", "short": b"hello world\n" * 3,
+    "fastq": fastq(800, 150), "runs": (b"I" * 500 + b"\n") * 400, "zeros": bytes(100000),
+    "random": bytes(rng.getrandbits(8) for _ in range(60000)),
+    "lowent": bytes(rng.choice(b"AB") for _ in range(100000)),
+    "text": b"the quick brown fox jumps over the lazy dog. " * 3000,
+    "period3": b"abc" * 30000, "period7": b"abcdefg" * 15000,
+}
+STRATEGIES = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]
+
+
+@pytest.mark.parametrize("name", sorted(DATA))
+def test_against_zlib_all_block_types_and_chunkings(name):
+    data = DATA[name]
+    for level in (0, 1, 6, 9):
+        for strat in STRATEGIES:
+            for memlevel in (1, 8):
+                comp = gz(data, level, strat, 31, memlevel)
+                for chunk in (1 << 22, 4096, 259, 7, 1):
+                    if chunk < 259 and len(data) > 20000:
+                        continue
+                    got, last = inflate(comp, len(data), chunk)
+                    assert last == 0 and got == data, (name, level, strat, memlevel, chunk)
+
+
+def test_multi_member_header_fields_and_trailing_garbage():
+    d1, d2 = DATA["fastq"][:60000], DATA["text"][:30000]
+    b = io.BytesIO()
+    with gzip.GzipFile(filename="some_name.fq", fileobj=b, mode="wb", mtime=5) as g:
+        g.write(d1)
+    multi = b.getvalue() + gz(d2, 9) + gz(b"") + gz(d1, 1)
+    for chunk in (1 << 22, 1000, 3):
+        got, last = inflate(multi, 2 * len(d1) + len(d2), chunk)
+        assert last == 0 and got == d1 + d2 + d1
+    got, _ = inflate(multi + b"\0\0\0garbage", 2 * len(d1) + len(d2), 1 << 22)
+    assert got == d1 + d2 + d1                              # like zlib: trailing garbage ignored
+    assert inflate(b"not gzip at all", 100, 4096) == (b"", -1)
+
+
+@pytest.mark.parametrize("wbits", [25, 27, 29])
+def test_small_windows(wbits):
+    comp = gz(DATA["text"], 6, zlib.Z_DEFAULT_STRATEGY, wbits)
+    assert inflate(comp, len(DATA["text"]), 1 << 20)[0] == DATA["text"]
+
+
+def test_corrupt_and_truncated_streams_never_crash():
+    data = DATA["fastq"]
+    comp = bytearray(gz(data, 6))
+    for _ in range(300):
+        c = bytearray(comp)
+        p = rng.randrange(10, len(c))
+        c[p] ^= 1 << rng.randrange(8)
+        inflate(bytes(c), len(data), 1 << 16)               # any result, no crash, bounded output
+    for cut in (5, 18, 19, 100, len(comp) // 2, len(comp) - 4):
+        got, _ = inflate(bytes(comp[:cut]), len(data), 1 << 16)
+        ref = zlib.decompressobj(31).decompress(bytes(comp[:cut]))
+        assert got[:len(ref)] == ref[:len(got)]             # a prefix of the truth
+
+
+def test_reader_gives_the_same_records_through_zlib_fallback(monkeypatch):
+    """QUACK_ZLIB=1 routes gzip through zlib's gzread; records must not change"""
+    for f in ("uniform100.fq.gz", "ragged100_2member.fq.gz", "long40.fq.gz"):
+        fast, _ = product_tokenize(cases.inp(f))
+        monkeypatch.setenv("QUACK_ZLIB", "1")
+        slow, _ = product_tokenize(cases.inp(f))
+        monkeypatch.delenv("QUACK_ZLIB")
+        assert fast == slow and len(fast) > 0
