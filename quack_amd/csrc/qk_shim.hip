@@ -554,6 +554,8 @@ int qk_accum_commit(qk_accum *a, uint64_t n_reads, uint64_t total, int offsets_u
 int qk_accum_submit(qk_accum *a, const uint8_t *seq, const uint8_t *qual,
                     const uint64_t *offsets, uint64_t n_reads) {
   if (!a || !offsets || (n_reads && (!seq || !qual))) return fail(QK_EINVAL, "NULL argument");
+  for (uint64_t k = 0; k < n_reads; ++k)
+    if (offsets[k + 1] < offsets[k]) return fail(QK_EINVAL, "offsets not monotonic at read %llu", (unsigned long long)k);
   uint64_t i = 0;
   while (i < n_reads) {
     uint8_t *hs, *hq;
@@ -572,7 +574,10 @@ int qk_accum_submit(qk_accum *a, const uint8_t *seq, const uint8_t *qual,
     memcpy(hs, seq + base, bytes);
     memcpy(hq, qual + base, bytes);
     for (uint64_t k = i; k <= j; ++k) ho[k - i] = offsets[k] - base;
-    if ((rc = qk_accum_commit(a, j - i, bytes, 1, 0))) return rc;
+    if ((rc = qk_accum_commit(a, j - i, bytes, 1, 0))) {
+      a->held_slot = -1;   // the copying feed owns the slot: give it back on failure
+      return rc;
+    }
     i = j;
   }
   return QK_OK;
@@ -598,7 +603,10 @@ int qk_accum_submit_fixed(qk_accum *a, const uint8_t *seq, const uint8_t *qual,
     }
     memcpy(hs, seq + i * read_len, n * read_len);
     memcpy(hq, qual + i * read_len, n * read_len);
-    if ((rc = qk_accum_commit(a, n, n * read_len, 0, read_len))) return rc;
+    if ((rc = qk_accum_commit(a, n, n * read_len, 0, read_len))) {
+      a->held_slot = -1;
+      return rc;
+    }
     i += n;
   }
   return QK_OK;
