@@ -146,8 +146,11 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 // counters and only flush / clear their LDS histogram when they change tile (or
 // their u16 counters could overflow), so the number of table flushes is
 // ~ tiles + workgroups instead of tiles x slices.
+#ifndef QK_MIN_WAVES_PER_SIMD
+#define QK_MIN_WAVES_PER_SIMD 1   // experiments: (T/256)*k asks for k workgroups per CU
+#endif
 template <int T, int U, bool FIXED, int MODE, bool ADAPT = false>
-__global__ __launch_bounds__(T) void hist_kernel(const HistParams p) {
+__global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
   extern __shared__ uint32_t lds[];
   const uint32_t tid = threadIdx.x;
   const uint32_t CH = p.ch;
