@@ -47,7 +47,7 @@ WORKLOADS = {
 }
 
 
-def make_batch(w, seed, device):
+def make_batch(w, seed, device, quality="uniform"):
     g = torch.Generator(device=device).manual_seed(seed)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     if w["ragged"]:
@@ -66,7 +66,13 @@ def make_batch(w, seed, device):
     for a in range(0, total, step):
         b = min(total, a + step)
         seq[a:b] = lut[torch.randint(0, 4, (b - a,), generator=g, device=device)]
-        qual[a:b] = (33 + torch.randint(q_lo, q_hi + 1, (b - a,), generator=g, device=device)).to(torch.uint8)
+        if quality == "novaseq4":
+            levels = torch.tensor([33 + 2, 33 + 12, 33 + 23, 33 + 37], dtype=torch.uint8, device=device)
+            u = torch.rand(b - a, generator=g, device=device)
+            idx = (u > 0.03).long() + (u > 0.08).long() + (u > 0.20).long()
+            qual[a:b] = levels[idx]
+        else:
+            qual[a:b] = (33 + torch.randint(q_lo, q_hi + 1, (b - a,), generator=g, device=device)).to(torch.uint8)
     return seq, qual, d_off, total, max_len
 
 
@@ -123,6 +129,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--device", type=int, default=None, help="force this device for every rank")
     ap.add_argument("--reads", type=int, default=None, help="override reads per GPU (rehearsals)")
+    ap.add_argument("--quality", default="uniform", choices=["uniform", "novaseq4"],
+                    help="novaseq4: Q in {2,12,23,37} with 3/5/12/80 %% (stress for same-bin LDS atomics)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,7 +152,7 @@ def main():
     if args.reads:
         w["n"] = args.reads
     bits, ads = synthetic_adapter_bits() if w["adapters"] else (None, None)
-    seq, qual, d_off, total, max_len = make_batch(w, seed=2 + rank, device=device)
+    seq, qual, d_off, total, max_len = make_batch(w, seed=2 + rank, device=device, quality=args.quality)
     n = w["n"]
     alg_bytes = 2.0 * total + (8.0 * n if d_off is not None else 0.0)
 
@@ -202,7 +210,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": w["label"], "reads_per_gpu": n, "bases_per_gpu_per_step": total,
+            "config": {"workload": w["label"] + ("" if args.quality == "uniform" else " [quality: %s]" % args.quality),
+                       "reads_per_gpu": n, "bases_per_gpu_per_step": total,
                        "resident": "HBM", "parallelism": "batch-sharded x%d, one all-reduce of u64 tables" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -14,199 +14,17 @@
  *     as long as the sequence; a length mismatch or a missing quality ends the
  *     stream (the reference's read loop stops at the first negative return,
  *     quack.c:193).
+ * Input bytes come in blocks from source.c (parallel / threaded inflate).
  * Unlike kseq, bytes go straight into the caller's batch arrays (the pinned
  * staging buffers of the C-ABI): one memchr + one memcpy per line.  A record
  * that does not fit in the rest of the batch is parked on the heap and opens
  * the next batch.
  */
-#include <fcntl.h>
-#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-#include <zlib.h>
 
-#include "inflate_fast.h"
 #include "quack_host.h"
-
-enum { QKH_IO_BUF = 4 << 20, QKH_RING = 4 };
-
-/* ---------------------------------------------------------------- byte source
- * Decompressed bytes arrive in 4 MiB blocks from a producer thread, so that
- * inflate (78 % of the reference's wall time) overlaps parsing,
- * the PCIe copies and the kernels.  Three producers:
- *   - a regular gzip file is memory-mapped and decoded by inflate_fast.c
- *     (about 1.65x zlib on FASTQ); every block carries the previous 32 KiB of
- *     output in front of its data, which is all DEFLATE can refer back to;
- *   - anything else that is gzip (pipes, QUACK_ZLIB=1) goes through zlib's
- *     gzread like the reference (quack.c:160,187);
- *   - a regular file that is not gzip is read with plain read(2).
- */
-enum { QKH_HIST = 32768 };
-typedef struct {
-  uint8_t *base;   /* allocation: QKH_HIST bytes of history + QKH_IO_BUF of data */
-  uint8_t *data;   /* base + QKH_HIST */
-  size_t len;
-} block;
-
-typedef struct {
-  pthread_t thread;
-  pthread_mutex_t mu;
-  pthread_cond_t can_produce, can_consume;
-  block ring[QKH_RING];
-  unsigned head, tail;      /* produced / consumed block counters */
-  int done;                 /* producer finished (EOF or error) */
-  int stop;                 /* consumer asks the producer to quit */
-  int started;
-  gzFile gz;
-  int fd;                   /* >= 0: plain file */
-  /* fast gzip path */
-  const uint8_t *map;
-  size_t map_len;
-  qkh_inflate *zf;
-  uint8_t *hist;            /* last QKH_HIST bytes produced */
-  size_t hist_len;
-} source;
-
-static void *source_main(void *arg) {
-  source *s = arg;
-  for (;;) {
-    block *b;
-    long n;
-    pthread_mutex_lock(&s->mu);
-    while (!s->stop && s->head - s->tail == QKH_RING) pthread_cond_wait(&s->can_produce, &s->mu);
-    if (s->stop) {
-      pthread_mutex_unlock(&s->mu);
-      break;
-    }
-    b = &s->ring[s->head % QKH_RING];
-    pthread_mutex_unlock(&s->mu);
-    if (s->zf) {
-      /* previous output in front of this block's data, then decode into it */
-      size_t got = 0;
-      long k = 1;
-      memcpy(b->data - s->hist_len, s->hist, s->hist_len);
-      while (got < QKH_IO_BUF && (k = qkh_inflate_read(s->zf, b->data + got, QKH_IO_BUF - got, s->hist_len + got)) > 0)
-        got += (size_t)k;
-      n = (long)got;
-      if (got >= QKH_HIST) {
-        memcpy(s->hist, b->data + got - QKH_HIST, QKH_HIST);
-        s->hist_len = QKH_HIST;
-      } else if (got) {
-        const size_t keep = s->hist_len + got > QKH_HIST ? QKH_HIST - got : s->hist_len;
-        memmove(s->hist, s->hist + s->hist_len - keep, keep);
-        memcpy(s->hist + keep, b->data, got);
-        s->hist_len = keep + got;
-      }
-    } else if (s->fd >= 0) {
-      size_t got = 0;
-      n = 1;
-      while (got < QKH_IO_BUF && (n = read(s->fd, b->data + got, QKH_IO_BUF - got)) > 0) got += (size_t)n;
-      n = (long)got;
-    } else {
-      n = gzread(s->gz, b->data, QKH_IO_BUF);
-    }
-    pthread_mutex_lock(&s->mu);
-    if (n <= 0) {
-      s->done = 1;
-      pthread_cond_signal(&s->can_consume);
-      pthread_mutex_unlock(&s->mu);
-      break;
-    }
-    b->len = (size_t)n;
-    s->head++;
-    pthread_cond_signal(&s->can_consume);
-    pthread_mutex_unlock(&s->mu);
-  }
-  return NULL;
-}
-
-static int source_open(source *s, const char *path) {
-  struct stat st;
-  memset(s, 0, sizeof *s);
-  s->fd = -1;
-  /* gzopen like the reference (works on pipes too); a regular file that is not
-   * gzip is then read directly, without zlib's pass-through copy */
-  s->gz = gzopen(path, "rb");
-  if (!s->gz) return -1;
-  gzbuffer(s->gz, 1 << 20);
-  if (stat(path, &st) == 0 && S_ISREG(st.st_mode)) {
-    int fd = open(path, O_RDONLY);
-    if (fd >= 0 && gzdirect(s->gz)) {
-      gzclose(s->gz);
-      s->gz = NULL;
-      s->fd = fd;
-#ifdef POSIX_FADV_SEQUENTIAL
-      posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
-#endif
-    } else if (fd >= 0 && st.st_size > 0 && !getenv("QUACK_ZLIB")) {
-      void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-      close(fd);
-      if (m != MAP_FAILED) {
-        madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-        s->zf = malloc(sizeof *s->zf);
-        s->hist = malloc(QKH_HIST);
-        if (!s->zf || !s->hist) return -1;
-        s->map = m;
-        s->map_len = (size_t)st.st_size;
-        qkh_inflate_init(s->zf, s->map, s->map_len);
-        gzclose(s->gz);
-        s->gz = NULL;
-      }
-    } else if (fd >= 0) {
-      close(fd);
-    }
-  }
-  for (int i = 0; i < QKH_RING; i++) {
-    if (!(s->ring[i].base = malloc(QKH_HIST + QKH_IO_BUF))) return -1;
-    s->ring[i].data = s->ring[i].base + QKH_HIST;
-  }
-  pthread_mutex_init(&s->mu, NULL);
-  pthread_cond_init(&s->can_produce, NULL);
-  pthread_cond_init(&s->can_consume, NULL);
-  if (pthread_create(&s->thread, NULL, source_main, s)) return -1;
-  s->started = 1;
-  return 0;
-}
-
-/* release the block handed out last and wait for the next one; 0 at the end */
-static int source_next(source *s, int release_prev, const uint8_t **data, size_t *len) {
-  pthread_mutex_lock(&s->mu);
-  if (release_prev) {
-    s->tail++;
-    pthread_cond_signal(&s->can_produce);
-  }
-  while (s->head == s->tail && !s->done) pthread_cond_wait(&s->can_consume, &s->mu);
-  if (s->head == s->tail) {
-    pthread_mutex_unlock(&s->mu);
-    return 0;
-  }
-  *data = s->ring[s->tail % QKH_RING].data;
-  *len = s->ring[s->tail % QKH_RING].len;
-  pthread_mutex_unlock(&s->mu);
-  return 1;
-}
-
-static void source_close(source *s) {
-  if (s->started) {
-    pthread_mutex_lock(&s->mu);
-    s->stop = 1;
-    pthread_cond_signal(&s->can_produce);
-    pthread_mutex_unlock(&s->mu);
-    pthread_join(s->thread, NULL);
-    pthread_mutex_destroy(&s->mu);
-    pthread_cond_destroy(&s->can_produce);
-    pthread_cond_destroy(&s->can_consume);
-  }
-  if (s->gz) gzclose(s->gz);
-  if (s->fd >= 0) close(s->fd);
-  if (s->map) munmap((void *)s->map, s->map_len);
-  free(s->zf);
-  free(s->hist);
-  for (int i = 0; i < QKH_RING; i++) free(s->ring[i].base);
-}
+#include "source.h"
 
 /* where the bytes of the record being parsed go */
 typedef struct {
@@ -218,7 +36,7 @@ typedef struct {
 } sink;
 
 struct qkh_reader {
-  source src;
+  qkh_source *src;
   const uint8_t *buf;  /* the source block being parsed */
   size_t pos, lim;
   int have_block;
@@ -234,7 +52,7 @@ struct qkh_reader {
 static int refill(qkh_reader *r) {
   if (r->eof) return 0;
   r->pos = 0;
-  if (!source_next(&r->src, r->have_block, &r->buf, &r->lim)) {
+  if (!qkh_source_next(r->src, &r->buf, &r->lim)) {
     r->lim = 0;
     r->eof = 1;
     r->have_block = 0;
@@ -353,8 +171,8 @@ static long parse_record(qkh_reader *r, sink *sq, sink *ql, int *is_fastq) {
 qkh_reader *qkh_reader_open(const char *path) {
   qkh_reader *r = calloc(1, sizeof *r);
   if (!r) return NULL;
-  if (source_open(&r->src, path)) {
-    source_close(&r->src);
+  r->src = qkh_source_open(path);
+  if (!r->src) {
     free(r);
     return NULL;
   }
@@ -363,7 +181,7 @@ qkh_reader *qkh_reader_open(const char *path) {
 
 void qkh_reader_close(qkh_reader *r) {
   if (!r) return;
-  source_close(&r->src);
+  qkh_source_close(r->src);
   free(r->park_seq);
   free(r->park_qual);
   free(r);

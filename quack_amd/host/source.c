@@ -1,0 +1,407 @@
+/*
+ * source.c — where the tokenizer's bytes come from.
+ *
+ * Decompressed bytes arrive in 4 MiB blocks, in stream order, from producer
+ * threads, so that inflate (78 % of the reference's wall time)
+ * overlaps parsing, the PCIe copies and the kernels.  Four producers:
+ *
+ *   bgzf     a BGZF file (gzip members of <= 64 KiB that carry their own size
+ *            in a "BC" extra field — bgzip, htslib): a dispatcher walks the
+ *            member headers and a pool of workers decodes runs of members in
+ *            parallel, each straight into its ring block;
+ *   inflate  any other regular gzip file is memory-mapped and decoded by one
+ *            thread with inflate_fast.c (~1.65x zlib on FASTQ); every block
+ *            carries the previous 32 KiB of output in front of its data, which
+ *            is all DEFLATE can refer back to;
+ *   zlib     gzip from a pipe, or QUACK_ZLIB=1: zlib's gzread, like the
+ *            reference (quack.c:160,187);
+ *   plain    a regular file that is not gzip: read(2).
+ *
+ * Whatever a producer cannot decode ends the stream at that byte — the
+ * reference's read loop also just stops when gzread fails (quack.c:193).
+ */
+#include "source.h"
+
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include "inflate_fast.h"
+
+enum { BLOCK_BYTES = 4 << 20, HIST = 32768, SERIAL_RING = 4, MAX_WORKERS = 32 };
+
+typedef struct {
+  uint8_t *base;        /* allocation: HIST bytes of history + BLOCK_BYTES of data */
+  uint8_t *data;        /* base + HIST */
+  size_t len;
+  int ready;            /* filled; the consumer may take it */
+  /* bgzf task */
+  const uint8_t *in;
+  size_t in_len, expect;
+} block;
+
+struct qkh_source {
+  pthread_mutex_t mu;
+  pthread_cond_t space, filled, work;
+  block *ring;
+  unsigned n_ring;
+  unsigned head;        /* blocks assigned to a producer so far */
+  unsigned tail;        /* blocks consumed so far */
+  unsigned next_work;   /* bgzf: next assigned block without a worker */
+  int holding;          /* the consumer still holds block tail */
+  int done;             /* no further block will be assigned */
+  int ended;            /* the consumer met an undecodable run: stream over */
+  int stop;             /* closing */
+  int n_threads;
+  pthread_t threads[MAX_WORKERS + 1];
+  char kind[32];
+  /* inputs */
+  gzFile gz;
+  int fd;
+  const uint8_t *map;
+  size_t map_len;
+  /* serial inflate_fast */
+  qkh_inflate *zf;
+  uint8_t *hist;
+  size_t hist_len;
+  /* bgzf */
+  qkh_inflate *worker_z[MAX_WORKERS];
+  int n_workers;
+};
+
+/* ------------------------------------------------------------- ring basics */
+static block *claim_block(qkh_source *s) { /* producer side; NULL when closing */
+  block *b;
+  pthread_mutex_lock(&s->mu);
+  while (!s->stop && s->head - s->tail == s->n_ring) pthread_cond_wait(&s->space, &s->mu);
+  if (s->stop) {
+    pthread_mutex_unlock(&s->mu);
+    return NULL;
+  }
+  b = &s->ring[s->head % s->n_ring];
+  b->ready = 0;
+  b->len = 0;
+  b->in = NULL;
+  pthread_mutex_unlock(&s->mu);
+  return b;
+}
+
+static void finish_stream(qkh_source *s) {
+  pthread_mutex_lock(&s->mu);
+  s->done = 1;
+  pthread_cond_broadcast(&s->filled);
+  pthread_cond_broadcast(&s->work);
+  pthread_mutex_unlock(&s->mu);
+}
+
+/* ---------------------------------------------------------- serial producer */
+static size_t fill_serial(qkh_source *s, block *b) {
+  size_t got = 0;
+  if (s->zf) {
+    long k = 1;
+    memcpy(b->data - s->hist_len, s->hist, s->hist_len);
+    while (got < BLOCK_BYTES && (k = qkh_inflate_read(s->zf, b->data + got, BLOCK_BYTES - got, s->hist_len + got)) > 0)
+      got += (size_t)k;
+    if (got >= HIST) {
+      memcpy(s->hist, b->data + got - HIST, HIST);
+      s->hist_len = HIST;
+    } else if (got) {
+      const size_t keep = s->hist_len + got > HIST ? HIST - got : s->hist_len;
+      memmove(s->hist, s->hist + s->hist_len - keep, keep);
+      memcpy(s->hist + keep, b->data, got);
+      s->hist_len = keep + got;
+    }
+  } else if (s->fd >= 0) {
+    long n = 1;
+    while (got < BLOCK_BYTES && (n = read(s->fd, b->data + got, BLOCK_BYTES - got)) > 0) got += (size_t)n;
+  } else {
+    int n = gzread(s->gz, b->data, BLOCK_BYTES);
+    got = n > 0 ? (size_t)n : 0;
+  }
+  return got;
+}
+
+static void *serial_main(void *arg) {
+  qkh_source *s = arg;
+  for (;;) {
+    block *b = claim_block(s);
+    size_t got;
+    if (!b) break;
+    got = fill_serial(s, b);
+    if (!got) break;
+    pthread_mutex_lock(&s->mu);
+    b->len = got;
+    b->ready = 1;
+    s->head++;
+    pthread_cond_broadcast(&s->filled);
+    pthread_mutex_unlock(&s->mu);
+  }
+  finish_stream(s);
+  return NULL;
+}
+
+/* -------------------------------------------------------------------- bgzf */
+/* total size of the BGZF member at p (0 if p does not start one) */
+static size_t bgzf_member_size(const uint8_t *p, const uint8_t *end) {
+  if (end - p < 28 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+  size_t xlen = p[10] | ((size_t)p[11] << 8);
+  const uint8_t *x = p + 12, *xe = x + xlen;
+  if (xe > end) return 0;
+  while (xe - x >= 4) {
+    size_t slen = x[2] | ((size_t)x[3] << 8);
+    if (x[0] == 'B' && x[1] == 'C' && slen == 2 && xe - x >= 6) {
+      size_t bsize = (x[4] | ((size_t)x[5] << 8)) + 1;
+      return (bsize >= 12 + xlen + 8 && (size_t)(end - p) >= bsize) ? bsize : 0;
+    }
+    x += 4 + slen;
+  }
+  return 0;
+}
+
+static void *bgzf_dispatch_main(void *arg) {
+  qkh_source *s = arg;
+  const uint8_t *p = s->map, *end = s->map + s->map_len;
+  while (p < end) {
+    const uint8_t *start = p;
+    size_t out = 0;
+    while (p < end) {
+      size_t bsize = bgzf_member_size(p, end), isize;
+      if (!bsize) break;
+      isize = p[bsize - 4] | ((size_t)p[bsize - 3] << 8) | ((size_t)p[bsize - 2] << 16) | ((size_t)p[bsize - 1] << 24);
+      if (isize > 65536) break; /* not a BGZF block after all */
+      if (out + isize > BLOCK_BYTES) break;
+      out += isize;
+      p += bsize;
+    }
+    if (p == start) break; /* a member that is not BGZF: the tail is decoded serially below */
+    block *b = claim_block(s);
+    if (!b) return NULL;
+    pthread_mutex_lock(&s->mu);
+    b->in = start;
+    b->in_len = (size_t)(p - start);
+    b->expect = out;
+    s->head++;
+    pthread_cond_signal(&s->work);
+    pthread_mutex_unlock(&s->mu);
+  }
+  if (p < end) {
+    /* rest of the file is ordinary gzip (or garbage): one serial decoder from
+     * here; members are independent, so it needs no history */
+    s->zf = malloc(sizeof *s->zf);
+    s->hist = malloc(HIST);
+    if (s->zf && s->hist) {
+      qkh_inflate_init(s->zf, p, (size_t)(end - p));
+      for (;;) {
+        block *b = claim_block(s);
+        size_t got;
+        if (!b) return NULL;
+        b->in = NULL;
+        got = fill_serial(s, b);
+        if (!got) break;
+        pthread_mutex_lock(&s->mu);
+        b->len = got;
+        b->ready = 1;   /* in == NULL: the workers skip it */
+        s->head++;
+        pthread_cond_broadcast(&s->filled);
+        pthread_mutex_unlock(&s->mu);
+      }
+    }
+  }
+  finish_stream(s);
+  return NULL;
+}
+
+typedef struct {
+  qkh_source *s;
+  qkh_inflate *z;
+} worker_arg;
+
+static void *bgzf_worker_main(void *arg) {
+  worker_arg *wa = arg;
+  qkh_source *s = wa->s;
+  qkh_inflate *z = wa->z;
+  free(wa);
+  for (;;) {
+    block *b;
+    size_t got = 0;
+    long k;
+    pthread_mutex_lock(&s->mu);
+    for (;;) {
+      /* blocks the dispatcher fills itself (ordinary gzip after the BGZF part) */
+      while (s->next_work < s->head && !s->ring[s->next_work % s->n_ring].in) s->next_work++;
+      if (s->next_work < s->head) break;
+      if (s->stop || s->done) {
+        pthread_mutex_unlock(&s->mu);
+        return NULL;
+      }
+      pthread_cond_wait(&s->work, &s->mu);
+    }
+    b = &s->ring[s->next_work++ % s->n_ring];
+    pthread_mutex_unlock(&s->mu);
+    qkh_inflate_init(z, b->in, b->in_len);
+    while (got < BLOCK_BYTES && (k = qkh_inflate_read(z, b->data + got, BLOCK_BYTES - got, got)) > 0) got += (size_t)k;
+    pthread_mutex_lock(&s->mu);
+    b->len = got;   /* != expect marks an undecodable run: the consumer ends the stream after it */
+    b->ready = 1;
+    pthread_cond_broadcast(&s->filled);
+    pthread_mutex_unlock(&s->mu);
+  }
+}
+
+/* --------------------------------------------------------------------- API */
+static int n_cpus(void) {
+  long n = sysconf(_SC_NPROCESSORS_ONLN);
+  const char *e = getenv("QUACK_THREADS");
+  if (e && atoi(e) > 0) n = atoi(e);
+  else if (n > 16) n = 16; /* the GPU box's share for one GPU */
+  if (n < 1) n = 1;
+  if (n > MAX_WORKERS) n = MAX_WORKERS;
+  return (int)n;
+}
+
+qkh_source *qkh_source_open(const char *path) {
+  qkh_source *s = calloc(1, sizeof *s);
+  struct stat st;
+  int workers = 0;
+  if (!s) return NULL;
+  s->fd = -1;
+  pthread_mutex_init(&s->mu, NULL);
+  pthread_cond_init(&s->space, NULL);
+  pthread_cond_init(&s->filled, NULL);
+  pthread_cond_init(&s->work, NULL);
+  /* gzopen like the reference (works on pipes too); regular files get the
+   * faster producers */
+  s->gz = gzopen(path, "rb");
+  if (!s->gz) goto fail;
+  gzbuffer(s->gz, 1 << 20);
+  snprintf(s->kind, sizeof s->kind, "zlib");
+  if (stat(path, &st) == 0 && S_ISREG(st.st_mode)) {
+    int fd = open(path, O_RDONLY);
+    if (fd >= 0 && gzdirect(s->gz)) {
+      gzclose(s->gz);
+      s->gz = NULL;
+      s->fd = fd;
+      snprintf(s->kind, sizeof s->kind, "plain");
+#ifdef POSIX_FADV_SEQUENTIAL
+      posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+#endif
+    } else if (fd >= 0 && st.st_size > 0 && !getenv("QUACK_ZLIB")) {
+      void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      close(fd);
+      if (m != MAP_FAILED) {
+        madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        s->map = m;
+        s->map_len = (size_t)st.st_size;
+        gzclose(s->gz);
+        s->gz = NULL;
+        if (bgzf_member_size(s->map, s->map + s->map_len) && !getenv("QUACK_NO_BGZF")) {
+          workers = n_cpus();
+          snprintf(s->kind, sizeof s->kind, "bgzf x%d", workers);
+        } else {
+          s->zf = malloc(sizeof *s->zf);
+          s->hist = malloc(HIST);
+          if (!s->zf || !s->hist) goto fail;
+          qkh_inflate_init(s->zf, s->map, s->map_len);
+          snprintf(s->kind, sizeof s->kind, "inflate_fast");
+        }
+      }
+    } else if (fd >= 0) {
+      close(fd);
+    }
+  }
+  s->n_ring = workers ? (unsigned)(2 * workers < SERIAL_RING ? SERIAL_RING : 2 * workers) : SERIAL_RING;
+  s->ring = calloc(s->n_ring, sizeof *s->ring);
+  if (!s->ring) goto fail;
+  for (unsigned i = 0; i < s->n_ring; i++) {
+    if (!(s->ring[i].base = malloc(HIST + BLOCK_BYTES))) goto fail;
+    s->ring[i].data = s->ring[i].base + HIST;
+  }
+  if (workers) {
+    if (pthread_create(&s->threads[s->n_threads], NULL, bgzf_dispatch_main, s)) goto fail;
+    s->n_threads++;
+    for (int i = 0; i < workers; i++) {
+      worker_arg *wa = malloc(sizeof *wa);
+      s->worker_z[i] = malloc(sizeof(qkh_inflate));
+      if (!wa || !s->worker_z[i]) {
+        free(wa);
+        break;
+      }
+      wa->s = s;
+      wa->z = s->worker_z[i];
+      s->n_workers = i + 1;
+      if (pthread_create(&s->threads[s->n_threads], NULL, bgzf_worker_main, wa)) {
+        free(wa);
+        break;
+      }
+      s->n_threads++;
+    }
+    if (s->n_threads < 2) goto fail;
+  } else {
+    if (pthread_create(&s->threads[0], NULL, serial_main, s)) goto fail;
+    s->n_threads = 1;
+  }
+  return s;
+fail:
+  qkh_source_close(s);
+  return NULL;
+}
+
+int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len) {
+  for (;;) {
+    block *b;
+    pthread_mutex_lock(&s->mu);
+    if (s->holding) {
+      s->holding = 0;
+      s->tail++;
+      pthread_cond_broadcast(&s->space);
+    }
+    while (!s->ended && !(s->tail < s->head && s->ring[s->tail % s->n_ring].ready) &&
+           !(s->done && s->tail == s->head))
+      pthread_cond_wait(&s->filled, &s->mu);
+    if (s->ended || s->tail == s->head) {
+      pthread_mutex_unlock(&s->mu);
+      return 0;
+    }
+    b = &s->ring[s->tail % s->n_ring];
+    if (b->in && b->len != b->expect) s->ended = 1;   /* deliver what it produced, then stop */
+    *data = b->data;
+    *len = b->len;
+    s->holding = 1;
+    pthread_mutex_unlock(&s->mu);
+    if (*len) return 1;
+    /* an empty run (e.g. only the BGZF end-of-file marker): take the next one */
+  }
+}
+
+const char *qkh_source_kind(const qkh_source *s) { return s->kind; }
+
+void qkh_source_close(qkh_source *s) {
+  if (!s) return;
+  pthread_mutex_lock(&s->mu);
+  if (!s->stop) s->stop = 1;
+  pthread_cond_broadcast(&s->space);
+  pthread_cond_broadcast(&s->work);
+  pthread_cond_broadcast(&s->filled);
+  pthread_mutex_unlock(&s->mu);
+  for (int i = 0; i < s->n_threads; i++) pthread_join(s->threads[i], NULL);
+  pthread_mutex_destroy(&s->mu);
+  pthread_cond_destroy(&s->space);
+  pthread_cond_destroy(&s->filled);
+  pthread_cond_destroy(&s->work);
+  if (s->gz) gzclose(s->gz);
+  if (s->fd >= 0) close(s->fd);
+  if (s->map) munmap((void *)s->map, s->map_len);
+  free(s->zf);
+  free(s->hist);
+  for (int i = 0; i < MAX_WORKERS; i++) free(s->worker_z[i]);
+  if (s->ring)
+    for (unsigned i = 0; i < s->n_ring; i++) free(s->ring[i].base);
+  free(s->ring);
+  free(s);
+}

@@ -1,0 +1,19 @@
+/* source.h — decompressed-byte source of the tokenizer (see source.c). */
+#ifndef QKH_SOURCE_H
+#define QKH_SOURCE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct qkh_source qkh_source;
+
+qkh_source *qkh_source_open(const char *path);
+/* Release the block handed out by the previous call (if any) and wait for the
+ * next one, in stream order.  Returns 1 with *data / *len set, or 0 at the end
+ * of the stream (EOF or the first undecodable byte, like a failing gzread). */
+int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len);
+void qkh_source_close(qkh_source *s);
+/* "zlib", "inflate_fast", "bgzf xN" or "plain": which producer is running */
+const char *qkh_source_kind(const qkh_source *s);
+
+#endif

@@ -66,11 +66,50 @@ static size_t make_text(char *buf, size_t cap) {
   return n;
 }
 
+static void bgzf_block(FILE *f, const unsigned char *data, size_t n, int level) {
+  unsigned char out[70000];
+  z_stream s;
+  memset(&s, 0, sizeof s);
+  deflateInit2(&s, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+  s.next_in = (unsigned char *)data;
+  s.avail_in = (uInt)n;
+  s.next_out = out;
+  s.avail_out = sizeof out;
+  deflate(&s, Z_FINISH);
+  size_t clen = sizeof out - s.avail_out;
+  deflateEnd(&s);
+  unsigned bsize = (unsigned)(18 + clen + 8 - 1);
+  unsigned long crc = crc32(crc32(0, NULL, 0), data, (uInt)n);
+  unsigned char h[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (unsigned char)(bsize & 255), (unsigned char)(bsize >> 8)};
+  unsigned char t[8] = {(unsigned char)crc, (unsigned char)(crc >> 8), (unsigned char)(crc >> 16), (unsigned char)(crc >> 24),
+                        (unsigned char)n, (unsigned char)(n >> 8), (unsigned char)(n >> 16), (unsigned char)(n >> 24)};
+  fwrite(h, 1, 18, f);
+  fwrite(out, 1, clen, f);
+  fwrite(t, 1, 8, f);
+}
+
 static void write_file(const char *path, const char *data, size_t n, int gz) {
   FILE *f = fopen(path, "wb");
   if (!gz) {
     fwrite(data, 1, n, f);
     fclose(f);
+    return;
+  }
+  if (gz == 2) { /* BGZF: members of 1..6000 bytes, sometimes an ordinary gzip tail */
+    size_t done = 0, tail = rnd() % 4 == 0 ? (size_t)(rnd() % (n + 1)) : n;
+    while (done < tail) {
+      size_t k = 1 + (size_t)(rnd() % 6000);
+      if (k > tail - done) k = tail - done;
+      bgzf_block(f, (const unsigned char *)data + done, k, (int)(rnd() % 10));
+      done += k;
+    }
+    if (rnd() % 2) bgzf_block(f, (const unsigned char *)data, 0, 6);
+    fclose(f);
+    if (done < n) { /* ordinary member appended after the BGZF part */
+      gzFile g = gzopen(path, "ab6");
+      gzwrite(g, data + done, (unsigned)(n - done));
+      gzclose(g);
+    }
     return;
   }
   fclose(f);
@@ -151,7 +190,7 @@ int main(int argc, char **argv) {
   int failures = 0;
   for (int it = 0; it < iters; it++) {
     size_t n = make_text(text, 1 << 20);
-    for (int gz = 0; gz < 2; gz++) {
+    for (int gz = 0; gz < 3; gz++) {
       write_file(path, text, n, gz);
       static const size_t caps[4] = {1 << 20, 4096, 1000, 257};
       for (int c = 0; c < 4; c++) {

@@ -120,3 +120,64 @@ def test_reader_gives_the_same_records_through_zlib_fallback(monkeypatch):
         slow, _ = product_tokenize(cases.inp(f))
         monkeypatch.delenv("QUACK_ZLIB")
         assert fast == slow and len(fast) > 0
+
+
+# ------------------------------------------------------------------ BGZF
+def bgzf(data, block=65280, eof=True, level=6):
+    out = bytearray()
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof else [])
+    for c in chunks:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cd = co.compress(c) + co.flush()
+        bsize = 18 + len(cd) + 8 - 1
+        out += bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 66, 67, 2, 0, bsize & 255, bsize >> 8])
+        out += cd + zlib.crc32(c).to_bytes(4, "little") + len(c).to_bytes(4, "little")
+    return bytes(out)
+
+
+def source_kind(path):
+    H = _capi.host()
+    H.qkh_source_open.restype = ctypes.c_void_p
+    H.qkh_source_open.argtypes = [ctypes.c_char_p]
+    H.qkh_source_kind.restype = ctypes.c_char_p
+    H.qkh_source_kind.argtypes = [ctypes.c_void_p]
+    H.qkh_source_close.argtypes = [ctypes.c_void_p]
+    s = H.qkh_source_open(os.fsencode(path))
+    k = H.qkh_source_kind(s).decode()
+    H.qkh_source_close(s)
+    return k
+
+
+@pytest.mark.parametrize("block,threads", [(65280, "4"), (700, "3"), (65280, "1"), (5000, "16")])
+def test_bgzf_parallel_inflate_gives_the_same_records(tmp_path, monkeypatch, block, threads):
+    """a BGZF file is decoded by a worker pool, in order; the records must be
+    those of the same text as ordinary gzip"""
+    monkeypatch.setenv("QUACK_THREADS", threads)
+    text = fastq(30000, 150)                    # ~9.4 MB: several 4 MiB ring blocks
+    p_b, p_g = tmp_path / "x.fq.bgz", tmp_path / "x.fq.gz"
+    p_b.write_bytes(bgzf(text, block))
+    p_g.write_bytes(gz(text))
+    assert source_kind(str(p_b)).startswith("bgzf x") and source_kind(str(p_g)) == "inflate_fast"
+    a, _ = product_tokenize(str(p_b), 1 << 22, 1 << 16)
+    b, _ = product_tokenize(str(p_g), 1 << 22, 1 << 16)
+    assert len(a) == 30000 and a == b
+
+
+def test_bgzf_followed_by_ordinary_gzip_and_truncation(tmp_path):
+    t1, t2 = fastq(3000, 100), fastq(2000, 80)
+    p = tmp_path / "mixed.gz"
+    p.write_bytes(bgzf(t1, 4000, eof=False) + gz(t2))
+    want, _ = product_tokenize_text(tmp_path, t1 + t2)
+    got, _ = product_tokenize(str(p))
+    assert got == want and len(got) == 5000
+    # a BGZF file cut in the middle of a member: everything before it is delivered
+    whole = bgzf(t1, 4000)
+    p.write_bytes(whole[:len(whole) // 2])
+    got, _ = product_tokenize(str(p))
+    assert 0 < len(got) < 3000 and got == want[:len(got)]
+
+
+def product_tokenize_text(tmp_path, text):
+    q = tmp_path / "plain.fq"
+    q.write_bytes(text)
+    return product_tokenize(str(q))

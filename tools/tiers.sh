@@ -9,9 +9,10 @@ echo "== (iii) end-to-end CLI, 4M x 150 bp (0.6 Gbases)"
 ./tools/gen_fastq /tmp/e2e.fq.gz 4000000 150 150 2
 ./tools/gen_fastq /tmp/e2e.fq 4000000 150 150 2
 ./tools/gen_fastq /tmp/e2e_R2.fq.gz 4000000 150 150 5 2 30
+./tools/gen_fastq /tmp/e2e.fq.bgz 4000000 150 150 2
 ls -la /tmp/e2e.fq.gz /tmp/e2e.fq | awk '{print $5, $9}'
 TIMEFORMAT="%R s wall, %U s user"
-for f in /tmp/e2e.fq.gz /tmp/e2e.fq; do
+for f in /tmp/e2e.fq.gz /tmp/e2e.fq.bgz /tmp/e2e.fq; do
   for i in 1 2; do echo -n "quack -u $f : "; { time ./quack_amd/host/quack -u $f > /tmp/e2e.svg; } 2>&1; done
 done
 echo -n "quack -1 gz -2 gz (paired, 1.2 Gbases): "; { time ./quack_amd/host/quack -1 /tmp/e2e.fq.gz -2 /tmp/e2e_R2.fq.gz > /tmp/e2e.svg; } 2>&1
