@@ -299,17 +299,26 @@ void qkh_inflate_init(qkh_inflate *z, const uint8_t *data, size_t len) {
   z->state = QKH_Z_MEMBER;
 }
 
-/* copy `len` bytes from `dist` back; regions may overlap (dist < len) */
+/* copy `len` (3..258) bytes from `dist` back; regions may overlap (dist < len).
+ * May write up to 15 bytes past dst+len (the fast loop keeps that slack). */
 static inline void copy_match(uint8_t *dst, size_t dist, size_t len) {
   const uint8_t *src = dst - dist;
   if (dist >= 8) {
-    /* 8 bytes at a time; may write up to 7 bytes past dst+len (caller keeps slack) */
-    uint8_t *end = dst + len;
-    do {
-      memcpy(dst, src, 8);
-      dst += 8;
-      src += 8;
-    } while (dst < end);
+    /* most FASTQ matches are short: two unconditional 8-byte moves cover <= 16 */
+    memcpy(dst, src, 8);
+    memcpy(dst + 8, src + 8, 8);
+    if (len > 16) {
+      uint8_t *end = dst + len;
+      dst += 16;
+      src += 16;
+      do {
+        memcpy(dst, src, 8);
+        dst += 8;
+        src += 8;
+      } while (dst < end);
+    }
+  } else if (dist == 1) {
+    memset(dst, *src, len);   /* runs (quality plateaus) */
   } else {
     for (size_t i = 0; i < len; i++) dst[i] = src[i];
   }
@@ -364,7 +373,7 @@ long qkh_inflate_read(qkh_inflate *z, uint8_t *out, size_t cap, size_t history) 
         for (;;) {
           /* fast loop: >= 8 input bytes for the refill, room for a longest
            * match plus the copy's overshoot */
-          while (z->in_end - z->in >= NEED_INPUT_SLACK && o_end - o >= 258 + 16 + 8) {
+          while (z->in_end - z->in >= NEED_INPUT_SLACK && o_end - o >= 258 + 32) {
             uint32_t e;
             z->bitbuf |= load64(z->in) << z->bitcnt;
             z->in += (63 - z->bitcnt) >> 3;
