@@ -28,7 +28,7 @@ constexpr int kScanThreads = 256;
 constexpr int kCountThreads = 256;
 constexpr uint32_t kCountLdsPos = 4096;
 
-// base byte -> 2-bit code, quack.c:148-150,201 (see base_key_to_code)
+// base byte -> 2-bit code, quack.c:148-150,201 (letter key c & 31: T=20, C=3, G=7, else A)
 __device__ __forceinline__ uint32_t base_code(uint32_t c) {
   const uint32_t k = c & 31u;
   return k == 20u ? 1u : (k == 3u ? 2u : (k == 7u ? 3u : 0u));

@@ -27,8 +27,11 @@
 //     predecessor codes come from lanes -1 / -2 by DPP wave_shr:1 (two feeder
 //     lanes per wave re-compute the previous wave's last chunks); each of the 8
 //     windows is tested against an LDS-resident bit filter keyed by its low
-//     bits, and only filter hits consult the exact 2^20-bit table;
+//     bits, and only filter hits consult the exact table (LDS buckets of 15-bit
+//     remainders, or the global 2^20-bit set for huge adapter files);
 //     atomicMin(first_hit[read]).
+//   * long reads: position tiles x read slices; persistent workgroups pull
+//     slices from per-tile device counters and flush only when they change tile.
 // Quality rows are raw byte values (& 127); the mapping to quack's 91 score
 // bins is applied once, at flush time (histograms are linear, so re-binning
 // afterwards is exact).
@@ -53,7 +56,7 @@ struct HistParams {
   unsigned long long *table;    // planar [kOutRows][table_len]
   uint32_t *first_hit;          // per-read first adapter hit (ADAPT only)
   const uint32_t *kmer_bits;    // 2^20-bit exact table (ADAPT only)
-  const uint32_t *kmer_filter;  // small LDS-resident pre-filter (ADAPT only)
+  const uint32_t *kmer_filter;  // 2^18-bit window filter, copied into LDS (ADAPT only)
   uint64_t n_reads;
   uint64_t total_bytes;         // offsets[n_reads]; loads are clamped to it
   uint64_t reads_per_slice;     // <= kMaxReadsPerSlice
@@ -67,7 +70,6 @@ struct HistParams {
   uint32_t n_slices;            // read slices per tile; work items = n_tiles * n_slices
   uint32_t *queue;              // [n_tiles] slice counters (several tiles), or NULL
   uint32_t no_adapters;         // kmers == NULL semantics (quack.c:210,215)
-  uint32_t filter_mask;         // bits in kmer_filter - 1
   // exact LDS-resident membership table for the fused adapter path (0: use the
   // global bitset): 2^bucket_log2 buckets of eight u16 remainders
   const uint4 *kmer_buckets;

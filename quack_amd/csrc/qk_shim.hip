@@ -296,7 +296,6 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.first_hit = d_hit;
   hp.kmer_bits = a->d_kmer_bits;
   hp.kmer_filter = a->d_kmer_filter;
-  hp.filter_mask = a->filter_bits ? a->filter_bits - 1 : 0;
   hp.kmer_buckets = a->d_kmer_buckets;
   hp.bucket_log2 = pl.bucket_log2;
   hp.bucket_mul = a->bucket_mul;
