@@ -116,9 +116,10 @@ inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch) { return (4u * 
 constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit window filter = 32 KiB of LDS
 constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
-inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false, uint32_t bucket_log2 = 0) {
+constexpr uint32_t kStageReads = 1024;      // ragged: read descriptors staged in LDS per pass
+inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false) {
   return ((size_t)kQRows * hist_row_dwords(ch) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords : 0u)) * sizeof(uint32_t) +
-         (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0);
+         (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)kStageReads * 8 : 0);
 }
 
 // Exact membership in the bucket table: km' = km*mul mod 2^20 (a bijection for
@@ -166,6 +167,10 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   const uint8_t *filt8 = reinterpret_cast<const uint8_t *>(lds_filter);
   // (hist words, 5*TP, 4 and the filter are all multiples of 4 dwords: 16-byte aligned)
   uint4 *lds_buckets = reinterpret_cast<uint4 *>(lds_filter + kFusedFilterWords);
+  // ragged batches: descriptors {start - slice base, length [| index << 16]} of
+  // the reads of the current pass that reach this tile, compacted
+  uint2 *lds_list = reinterpret_cast<uint2 *>(
+      reinterpret_cast<char *>(lds_misc + 4u) + (ADAPT ? kFusedFilterWords * 4u + (p.bucket_log2 ? (16u << p.bucket_log2) : 0u) : 0u));
   const uint64_t TL = p.table_len;
 
   if (ADAPT) {
@@ -286,11 +291,6 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     if (r_end > p.n_reads) r_end = p.n_reads;
     const uint32_t slice_reads = r_end > r_begin ? (uint32_t)(r_end - r_begin) : 0u;
     if (FIXED && tile == 0) fixed_reads += slice_reads;
-    // reads past the slice are still addressable; this is how far the index
-    // may run before it leaves offsets[]
-    const uint64_t idx_room = p.n_reads > r_begin ? p.n_reads - r_begin : 0;
-    const uint32_t idx_limit = idx_room < 0xFFFFFFFFull ? (uint32_t)idx_room : 0xFFFFFFFFu;
-
     // 32-bit byte offsets relative to a 4-byte-aligned, workgroup-uniform base
     uint64_t slice_base = 0;
     if (slice_reads) slice_base = FIXED ? r_begin * p.read_len : p.offsets[r_begin];
@@ -304,68 +304,27 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     // windows ending before position 9 do not exist
     const uint32_t win_mask = cpos >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cpos)) - 1u));
 
-    // ragged batches: the start/end offsets of the NEXT iteration's reads are
-    // requested while the current iteration is processed, so the data loads
-    // never wait on an offsets round trip
-    uint64_t nx0[U], nx1[U];
-    auto fetch_offsets = [&](uint32_t it_next) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t rel = it_next + (uint32_t)u * RW + ri;
-        const uint32_t i0 = rel < idx_limit ? rel : idx_limit;
-        const uint32_t i1 = i0 < idx_limit ? i0 + 1u : idx_limit;
-        nx0[u] = obase[i0];
-        nx1[u] = obase[i1];
-      }
-    };
-    if (!FIXED && slice_reads) fetch_offsets(0);
-
-    for (uint32_t it = 0; it < slice_reads; it += RW * U) {
-      u32x3 q[U], s[U];
-      uint32_t nv[U], sk[U];
-      uint64_t cur0[U], cur1[U];
+    // Fixed-length batches: one pass over the slice, read r at r*L.  Ragged
+    // batches: passes of kStageReads reads; each pass first stages, in LDS, the
+    // descriptors of the reads that reach this tile (coalesced offsets[] read,
+    // wave-ballot compaction), so the loop below never waits on an offsets
+    // round trip and never spends a slot on a read that ends before the tile.
+    for (uint32_t pass = 0; pass < slice_reads; pass += FIXED ? slice_reads : kStageReads) {
+      uint32_t n_list = slice_reads;   // FIXED: every read of the slice
       if (!FIXED) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          cur0[u] = nx0[u];
-          cur1[u] = nx1[u];
-        }
-        if (it + RW * U < slice_reads) fetch_offsets(it + RW * U);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t rel = it + (uint32_t)u * RW + ri;   // read index within the slice
-        const bool ok = lane_on && rel < slice_reads;
-        uint32_t off, len;
-        if (FIXED) {
-          off = rel * p.read_len + cposp;
-          len = p.read_len;
-        } else {
-          len = (uint32_t)(cur1[u] - cur0[u]);
-          off = (uint32_t)(cur0[u] - base_al) + cpos;
-        }
-        // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
-        // compute codes like their originals but count nothing
-        uint32_t n_raw = (rel < slice_reads && ri < RW && len > cpos) ? len - cpos : 0u;
-        n_raw = n_raw > 8u ? 8u : n_raw;
-        nv[u] = lane_on ? n_raw : 0u;
-        off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
-        sk[u] = off & 3u;
-        off &= ~3u;
-        if (FIXED) {
-          q[u] = load12_aligned(qbase + off);
-          s[u] = load12_aligned(sbase + off);
-        } else {
-          // ragged: chunks past the end of their read fetch nothing (for 1-20 kb
-          // reads that is a third of all chunk slots)
-          q[u] = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-          s[u] = q[u];
-          if (n_raw != 0) {
-            q[u] = load12_aligned(qbase + off);
-            s[u] = load12_aligned(sbase + off);
+        const uint32_t nb = slice_reads - pass < kStageReads ? slice_reads - pass : kStageReads;
+        __syncthreads();               // the previous pass has been consumed
+        if (tid == 0) lds_misc[2] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < (nb + 63u) / 64u * 64u; i += T) {   // whole waves: ballot below
+          uint64_t o0 = 0;
+          uint32_t len = 0;
+          if (i < nb) {
+            o0 = obase[pass + i];
+            len = (uint32_t)(obase[pass + i + 1] - o0);
           }
-          // length_count / kmers==NULL bookkeeping by the owner of chunk 0
-          if (ok && ch == 0 && tile == 0) {
+          if (tile == 0 && i < nb) {
+            // length_count and the kmers==NULL count (quack.c:215-219), once per read
             n_gt10 += len > 10u ? 1u : 0u;
             if (len != 0) {
               const uint32_t lp = len - 1u;
@@ -375,8 +334,60 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
                 atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + lp], 1ull);
             }
           }
+          const bool reach = i < nb && len > P0;
+          const uint64_t vote = __builtin_amdgcn_ballot_w64(reach);
+          uint32_t wave_base = 0;
+          if (lane_id == 0 && vote) wave_base = atomicAdd(&lds_misc[2], (uint32_t)__builtin_popcountll(vote));
+          wave_base = __builtin_amdgcn_readfirstlane(wave_base);
+          if (reach) {
+            const uint32_t slot_i = wave_base + (uint32_t)__builtin_popcountll(vote & ((1ull << lane_id) - 1ull));
+            // ADAPT (single tile, len <= 576): the read's index within the pass rides in the high half
+            lds_list[slot_i] = make_uint2((uint32_t)(o0 - base_al), ADAPT ? (len | (i << 16)) : len);
+          }
         }
+        __syncthreads();
+        n_list = lds_misc[2];
       }
+
+      for (uint32_t it = 0; it < n_list; it += RW * U) {
+        u32x3 q[U], s[U];
+        uint32_t nv[U], sk[U], ridx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t rel = it + (uint32_t)u * RW + ri;   // index into the slice (FIXED) / the staged list
+          const bool in_list = rel < n_list && ri < RW;
+          uint32_t off, len;
+          if (FIXED) {
+            off = rel * p.read_len + cposp;
+            len = p.read_len;
+            ridx[u] = rel;
+          } else {
+            const uint2 e = lds_list[in_list ? rel : 0u];
+            off = e.x + cpos;
+            len = ADAPT ? (e.y & 0xFFFFu) : e.y;
+            ridx[u] = pass + (e.y >> 16);
+          }
+          // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
+          // compute codes like their originals but count nothing
+          uint32_t n_raw = (in_list && len > cpos) ? len - cpos : 0u;
+          n_raw = n_raw > 8u ? 8u : n_raw;
+          nv[u] = lane_on ? n_raw : 0u;
+          off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
+          sk[u] = off & 3u;
+          off &= ~3u;
+          if (FIXED) {
+            q[u] = load12_aligned(qbase + off);
+            s[u] = load12_aligned(sbase + off);
+          } else {
+            // chunks past the end of their read fetch nothing
+            q[u] = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            s[u] = q[u];
+            if (n_raw != 0) {
+              q[u] = load12_aligned(qbase + off);
+              s[u] = load12_aligned(sbase + off);
+            }
+          }
+        }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // bytes past the end of the read -> 0xFF: quality row 127 is discarded
@@ -467,14 +478,15 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
                 }
               }
               if (best != kNoHit)
-                atomicMin(&p.first_hit[r_begin + it + (uint32_t)u * RW + ri], best);
+                atomicMin(&p.first_hit[r_begin + ridx[u]], best);
             }
           }
         }
       }
-      if (MODE == 0 || MODE == 3) {
-        since_spill += U;
-        if (since_spill + U > 255u) spill();   // byte counters hold <= 255
+        if (MODE == 0 || MODE == 3) {
+          since_spill += U;
+          if (since_spill + U > 255u) spill();   // byte counters hold <= 255
+        }
       }
     }
     if (MODE == 0 || MODE == 3) spill();

@@ -164,9 +164,12 @@ constexpr unsigned kQueueTiles = 8192;  // counters per launch
 // (measured on 300 bp: two 152-wide tiles 1.78 ms, one 304-wide tile 1.10 ms).
 // Longer reads get tiles of <= 512 positions.  The grid is sized to residency:
 // workgroups per CU = what the LDS admits (at most 2 of 1024 threads).
-int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, Plan *pl) {
+int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, Plan *pl) {
   const uint32_t T = (uint32_t)a->threads, U = (uint32_t)a->unroll;
-  const uint32_t single_cap = a->adapters ? 448u : 576u;
+  // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
+  uint32_t single_cap = 576u;
+  while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, a->adapters, a->adapters ? a->bucket_log2 : 0, ragged) > 160 * 1024)
+    single_cap -= 32u;
   uint32_t cap = a->tile > 0 ? std::max<uint32_t>(8, (uint32_t)a->tile / 8 * 8) : single_cap;
   cap = std::min(cap, single_cap);
   uint32_t n_tiles = std::max<uint32_t>(1, (max_len + cap - 1) / cap);
@@ -189,8 +192,8 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, Plan *pl) {
   pl->rw = (pl->fused_adapters ? T / 64 * 62 : T) / pl->ch;
   const uint64_t step = (uint64_t)pl->rw * U;
   pl->bucket_log2 = pl->fused_adapters ? a->bucket_log2 : 0;
-  if (pl->bucket_log2 && qk::hist_lds_bytes(pl->ch, true, pl->bucket_log2) > 160 * 1024) pl->bucket_log2 = 0;
-  const size_t lds = qk::hist_lds_bytes(pl->ch, pl->fused_adapters, pl->bucket_log2);
+  if (pl->bucket_log2 && qk::hist_lds_bytes(pl->ch, true, pl->bucket_log2, ragged) > 160 * 1024) pl->bucket_log2 = 0;
+  const size_t lds = qk::hist_lds_bytes(pl->ch, pl->fused_adapters, pl->bucket_log2, ragged);
   if (lds > 160 * 1024) return fail(QK_EINVAL, "LDS tile too large (%zu bytes)", lds);
   // residency: the kernels need 89-104 VGPRs, i.e. 4 waves per SIMD = 1024
   // threads per CU, and the LDS image must fit as many times
@@ -249,7 +252,7 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, d
 
 int launch_hist(qk_accum *a, const qk::HistParams &hp, bool fixed, int mode, bool adapt,
                 uint64_t n_blocks, hipStream_t st) {
-  const size_t lds = qk::hist_lds_bytes(hp.ch, adapt, hp.bucket_log2);
+  const size_t lds = qk::hist_lds_bytes(hp.ch, adapt, hp.bucket_log2, !fixed);
   dim3 grid((unsigned)n_blocks);
 #define QK_TU(TT, UU) \
   if (a->threads == TT && a->unroll == UU) return launch_hist_tu<TT, UU>(hp, fixed, mode, adapt, grid, lds, st);
@@ -286,7 +289,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     return QK_OK;
   }
   Plan pl;
-  rc = make_plan(a, n_reads, max_len, &pl);
+  rc = make_plan(a, n_reads, max_len, d_off != nullptr, &pl);
   if (rc) return rc;
   qk::HistParams hp{};
   hp.seq = d_seq;

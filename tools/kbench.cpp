@@ -172,7 +172,10 @@ int main(int argc, char **argv) {
   for (uint64_t r = 0; r < n_reads; ++r) {
     off[r] = total;
     uint32_t l = read_len;
-    if (ragged) l = 1 + (uint32_t)(splitmix(seed) % read_len);
+    if (ragged) {
+      const uint32_t lo = getenv("KB_RAGGED_LO") ? (uint32_t)atoi(getenv("KB_RAGGED_LO")) : 1u;   // lengths uniform in [lo, read_len]
+      l = lo + (uint32_t)(splitmix(seed) % (read_len - lo + 1));
+    }
     if (l > max_len) max_len = l;
     total += l;
   }
