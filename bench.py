@@ -44,10 +44,14 @@ WORKLOADS = {
                  label="10M-read synthetic 300 bp FASTQ + adapter FASTA (configs[2])"),
     "cfg5": dict(n=143_000, L=20000, ragged=(1000, 20000), adapters=False,
                  label="PacBio-style ragged 1-20 kb synthetic FASTQ (configs[4])"),
+    # configs[3]: paired 2 x 50M x 150 bp over 8 GPUs -> per GPU 2 x 6.25M reads; the two mates are two
+    # independent accumulations (quack.c:911-921); R2 qualities skewed lower
+    "cfg4": dict(n=6_250_000, L=150, ragged=None, adapters=False, paired=True,
+                 label="paired 2x50M 150 bp sharded over 8 GPUs: per-GPU share 2 x 6.25M reads (configs[3])"),
 }
 
 
-def make_batch(w, seed, device, quality="uniform"):
+def make_batch(w, seed, device, quality="uniform", q_hi_override=None):
     g = torch.Generator(device=device).manual_seed(seed)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     if w["ragged"]:
@@ -59,7 +63,7 @@ def make_batch(w, seed, device, quality="uniform"):
         q_lo, q_hi = 1, 60
     else:
         total, max_len, d_off = w["n"] * w["L"], w["L"], None
-        q_lo, q_hi = 2, 41
+        q_lo, q_hi = 2, (q_hi_override or 41)
     seq = torch.zeros(total + 16, dtype=torch.uint8, device=device)
     qual = torch.zeros(total + 16, dtype=torch.uint8, device=device)
     step = 1 << 28
@@ -157,12 +161,26 @@ def main():
     alg_bytes = 2.0 * total + (8.0 * n if d_off is not None else 0.0)
 
     acc = quack_amd.Accumulator(local, bits, max_len_hint=max_len)
+    mate = None
+    if w.get("paired"):
+        # the reverse mate: its own batch and its own accumulator
+        seq2, qual2, _, _, _ = make_batch(w, seed=1000 + rank, device=device, quality=args.quality, q_hi_override=30)
+        mate = quack_amd.Accumulator(local, bits, max_len_hint=max_len)
+
+    # paired: both mates on ONE stream, so that every launch has the GPU to itself and its
+    # HIP-event duration means something (on separate streams the two kernels would overlap)
+    side = torch.cuda.Stream(device) if mate is not None else None   # (the default stream's handle is NULL)
+    shared_stream = side.cuda_stream if side is not None else None
 
     def step():
-        acc.submit_device(seq, qual, d_off, n, total, max_len)
+        acc.submit_device(seq, qual, d_off, n, total, max_len, stream=shared_stream)
+        if mate is not None:
+            mate.submit_device(seq2, qual2, None, n, total, max_len, stream=shared_stream)
 
     def fence():
         acc.sync()
+        if mate is not None:
+            mate.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -171,11 +189,15 @@ def main():
         step()
     fence()
     acc.timing(True)
+    if mate is not None:
+        mate.timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     if world > 1:
         qd.allreduce_accumulator(acc, via_host=args.backend == "gloo")   # the path's single exchange (RCCL over xGMI)
+        if mate is not None:
+            qd.allreduce_accumulator(mate, via_host=args.backend == "gloo")
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -183,6 +205,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms, launches = acc.timing_read()
+    mates = 2 if mate is not None else 1
+    if mate is not None:
+        ms2, l2 = mate.timing_read()
+        kernel_ms, launches = kernel_ms + ms2, launches + l2
 
     # sanity: the counters must add up (every base carries one score and one content bin)
     sd = acc.finish()
@@ -204,14 +230,14 @@ def main():
             traffic = json.load(open(tf)).get(args.workload)
         out = {
             "metric": "bases/sec on synthetic 150 bp FASTQ; achieved HBM GB/s vs peak",
-            "value": world * args.steps * total / elapsed,
+            "value": world * args.steps * total * mates / elapsed,
             "unit": "bases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": w["label"] + ("" if args.quality == "uniform" else " [quality: %s]" % args.quality),
-                       "reads_per_gpu": n, "bases_per_gpu_per_step": total,
+                       "reads_per_gpu": n * mates, "bases_per_gpu_per_step": total * mates,
                        "resident": "HBM", "parallelism": "batch-sharded x%d, one all-reduce of u64 tables" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -222,6 +248,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(seq, qual, d_off, n, total, w, ads)
         print(json.dumps(out), flush=True)
     acc.close()
+    if mate is not None:
+        sd2 = mate.finish()
+        if int(sd2.bases[:, 91:95].sum()) != (args.warmup + args.steps) * total * world:
+            raise SystemExit("counter check failed for the reverse mate")
+        mate.close()
     if world > 1:
         dist.destroy_process_group()
 
