@@ -309,10 +309,18 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     // descriptors of the reads that reach this tile (coalesced offsets[] read,
     // wave-ballot compaction), so the loop below never waits on an offsets
     // round trip and never spends a slot on a read that ends before the tile.
+    // the offsets of the next pass are requested one pass ahead (each thread
+    // stages the read `tid` of a pass), so staging never waits on memory
+    uint64_t pf0 = 0, pf1 = 0;
+    if (!FIXED && tid < slice_reads) {
+      pf0 = obase[tid];
+      pf1 = obase[tid + 1u];
+    }
     for (uint32_t pass = 0; pass < slice_reads; pass += FIXED ? slice_reads : kStageReads) {
       uint32_t n_list = slice_reads;   // FIXED: every read of the slice
       if (!FIXED) {
         const uint32_t nb = slice_reads - pass < kStageReads ? slice_reads - pass : kStageReads;
+        static_assert(T == 1024 || T == 512 || T == 256, "staging assumes kStageReads is a multiple of T");
         __syncthreads();               // the previous pass has been consumed
         if (tid == 0) lds_misc[2] = 0;
         __syncthreads();
@@ -320,8 +328,13 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           uint64_t o0 = 0;
           uint32_t len = 0;
           if (i < nb) {
-            o0 = obase[pass + i];
-            len = (uint32_t)(obase[pass + i + 1] - o0);
+            if (T == kStageReads) {    // one read per thread: it was prefetched
+              o0 = pf0;
+              len = (uint32_t)(pf1 - pf0);
+            } else {
+              o0 = obase[pass + i];
+              len = (uint32_t)(obase[pass + i + 1] - o0);
+            }
           }
           if (tile == 0 && i < nb) {
             // length_count and the kmers==NULL count (quack.c:215-219), once per read
@@ -347,6 +360,10 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         }
         __syncthreads();
         n_list = lds_misc[2];
+        if (T == kStageReads && pass + kStageReads + tid < slice_reads) {
+          pf0 = obase[pass + kStageReads + tid];
+          pf1 = obase[pass + kStageReads + tid + 1u];
+        }
       }
 
       for (uint32_t it = 0; it < n_list; it += RW * U) {
