@@ -65,7 +65,8 @@ struct HistParams {
   uint32_t n_tiles;             // position tiles
   uint32_t tile_pos;            // positions per tile (multiple of 8)
   uint32_t ch;                  // chunks per tile = tile_pos / 8
-  uint32_t row_dwords;          // LDS row stride: 4*ch rounded up to 32 banks
+  uint32_t row_dwords;          // LDS row stride: 4*replicas*ch rounded up to 32 banks
+  uint32_t replicas;            // column replicas (short reads: reads sharing a lane group get different banks)
   uint32_t reads_per_iter;      // chunk lanes per workgroup / ch
   uint32_t n_slices;            // read slices per tile; work items = n_tiles * n_slices
   uint32_t *queue;              // [n_tiles] slice counters (several tiles), or NULL
@@ -112,7 +113,13 @@ constexpr uint32_t kKeyT = 0x14141414u, kKeyC = 0x03030303u, kKeyG = 0x07070707u
 
 // LDS image (dwords): quality histogram [128][row_dwords] | base counters
 // [4: valid,T,C,G][8*ch] | length_count [8*ch] | misc[4]
-inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch) { return (4u * ch + 31u) / 32u * 32u; }
+// Short reads put several reads into one 32-lane group; with one column set
+// their lanes would collide on a bank (L=36: 7-way).  R replicas of the
+// columns, picked by (read index in the iteration) % R, spread them over the
+// banks; the flush sums the replicas.  R = 1 from 11 chunks per read up (two
+// reads per group collide at most 2-way, which the LDS hides).
+inline __host__ __device__ uint32_t hist_replicas(uint32_t ch) { return ch > 10u ? 1u : (32u + ch - 1u) / ch + 1u; }
+inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch) { return (4u * hist_replicas(ch) * ch + 31u) / 32u * 32u; }
 constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit window filter = 32 KiB of LDS
 constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
@@ -192,8 +199,9 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   const bool lane_on = lane_id >= feeders && ri < RW;
   const uint32_t row_bytes = 4u * RD;   // a multiple of 128 B: bank == column
   uint32_t qcol[4];
+  const uint32_t R = p.replicas;
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) qcol[jj] = (jj * CH + ch) * 4u;
+  for (int jj = 0; jj < 4; ++jj) qcol[jj] = ((jj * R + ri % R) * CH + ch) * 4u;
   const uint32_t one_lo = 1u, one_hi = 65536u;
 
   uint32_t n_gt10 = 0;        // reads longer than 10 (kmers==NULL path, quack.c:215)
@@ -241,8 +249,11 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     for (uint32_t row = 33u + wave; row <= 123u; row += T / 64) {  // quack.c:203: bin = byte - 33
       for (uint32_t pp = lane; pp < TP; pp += 64u) {
         const uint32_t c8 = pp >> 3, j = pp & 7u;
-        const uint32_t w = lds[row * RD + (j & 3u) * CH + c8];
-        const uint32_t c = (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
+        uint32_t c = 0;
+        for (uint32_t rep = 0; rep < R; ++rep) {
+          const uint32_t w = lds[row * RD + ((j & 3u) * R + rep) * CH + c8];
+          c += (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
+        }
         const uint32_t pos = P0 + pp;
         if (c != 0 && pos < p.table_len)
           atomicAdd(&p.table[(uint64_t)(row - 33u) * TL + pos], (unsigned long long)c);

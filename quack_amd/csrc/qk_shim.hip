@@ -217,7 +217,15 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   const uint64_t by_bytes = (0x7FFFFFFFull / std::max<uint32_t>(max_len, 1)) / step * step;
   if (by_bytes < step) return fail(QK_EINVAL, "reads of %u bytes are too long for one slice", max_len);
   rcap = std::min(rcap, by_bytes);
-  if (rps > rcap) rps = rcap;
+  if (rps > rcap) {
+    // more reads than one residency round may count in u16: whole rounds of
+    // equal slices, so that the last round is not a nearly empty one
+    const uint64_t per_round = (pl->dynamic ? 1 : resident) * rcap;
+    const uint64_t rounds = (n_reads + per_round - 1) / per_round;
+    n_slices = (pl->dynamic ? n_slices : resident) * rounds;
+    rps = round_up((n_reads + n_slices - 1) / n_slices, step);
+    if (rps > rcap) rps = rcap;
+  }
   pl->reads_per_slice = rps;
   pl->n_slices = (n_reads + rps - 1) / rps;
   if (pl->n_slices > 0xFFFFFF00ull) return fail(QK_EINVAL, "too many read slices");
@@ -319,6 +327,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     QK_HIP(hipMemsetAsync(hp.queue, 0, pl.n_tiles * sizeof(uint32_t), st));
   }
   hp.row_dwords = qk::hist_row_dwords(pl.ch);
+  hp.replicas = qk::hist_replicas(pl.ch);
   hp.no_adapters = a->adapters ? 0 : 1;
 
   TimedLaunch tl{};
