@@ -67,6 +67,7 @@ struct HistParams {
   uint32_t ch;                  // chunks per tile = tile_pos / 8
   uint32_t row_dwords;          // LDS row stride: 4*replicas*ch rounded up to 32 banks
   uint32_t replicas;            // column replicas (short reads: reads sharing a lane group get different banks)
+  uint32_t halo;                // ADAPT with several tiles: 2 extra lanes per read row cover the 16 positions before the tile
   uint32_t reads_per_iter;      // chunk lanes per workgroup / ch
   uint32_t n_slices;            // read slices per tile; work items = n_tiles * n_slices
   uint32_t *queue;              // [n_tiles] slice counters (several tiles), or NULL
@@ -126,7 +127,7 @@ constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr uint32_t kStageReads = 1024;      // ragged: read descriptors staged in LDS per pass
 inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false) {
   return ((size_t)kQRows * hist_row_dwords(ch) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords : 0u)) * sizeof(uint32_t) +
-         (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)kStageReads * 8 : 0);
+         (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)kStageReads * (adapt ? 12 : 8) : 0);
 }
 
 // Exact membership in the bucket table: km' = km*mul mod 2^20 (a bijection for
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   // the reads of the current pass that reach this tile, compacted
   uint2 *lds_list = reinterpret_cast<uint2 *>(
       reinterpret_cast<char *>(lds_misc + 4u) + (ADAPT ? kFusedFilterWords * 4u + (p.bucket_log2 ? (16u << p.bucket_log2) : 0u) : 0u));
+  uint32_t *lds_ridx = reinterpret_cast<uint32_t *>(lds_list + kStageReads);   // ADAPT: index of a staged read within its pass
   const uint64_t TL = p.table_len;
 
   if (ADAPT) {
@@ -193,10 +195,19 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   const uint32_t feeders = ADAPT ? 2u : 0u;
   const int32_t slot_signed = (int32_t)((tid >> 6) * (64u - feeders) + lane_id) - (int32_t)feeders;
   const uint32_t slot = slot_signed < 0 ? 0u : (uint32_t)slot_signed;
-  const uint32_t ri = slot / CH;
-  const uint32_t ch = slot - ri * CH;
+  // a read row is CH chunk lanes, preceded (ADAPT, several tiles) by two halo
+  // lanes that cover the 16 positions in front of the tile: they load and
+  // encode like any lane, so that the tile's first chunks find their
+  // predecessor codes in lanes -1 / -2, but they count nothing
+  const uint32_t H = ADAPT ? p.halo : 0u;
+  const uint32_t CHW = CH + H;
+  const uint32_t ri = slot / CHW;
+  const uint32_t chh = slot - ri * CHW;
+  const bool is_halo = chh < H;
+  const uint32_t ch = is_halo ? 0u : chh - H;        // column used for LDS addressing (halo lanes only ever add pads)
+  const int32_t ch_signed = (int32_t)chh - (int32_t)H;
   const uint32_t RW = p.reads_per_iter;
-  const bool lane_on = lane_id >= feeders && ri < RW;
+  const bool lane_on = lane_id >= feeders && !is_halo && ri < RW;
   const uint32_t row_bytes = 4u * RD;   // a multiple of 128 B: bank == column
   uint32_t qcol[4];
   const uint32_t R = p.replicas;
@@ -296,7 +307,10 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   // ---- one work item: reads [r_begin, r_end) x positions of `tile`
   auto process = [&](uint32_t tile, uint32_t slice) {
     const uint32_t P0 = tile * p.tile_pos;
-    const uint32_t cpos = P0 + 8u * ch;   // first position of the owned chunk
+    // first position of the owned chunk; halo lanes of tile 0 would sit before
+    // the read and are parked beyond any read instead (they then never load)
+    const int32_t cpos_s = (int32_t)P0 + 8 * ch_signed;
+    const uint32_t cpos = cpos_s < 0 ? 0xFFFFFF00u : (uint32_t)cpos_s;
     const uint64_t r_begin = (uint64_t)slice * p.reads_per_slice;
     uint64_t r_end = r_begin + p.reads_per_slice;
     if (r_end > p.n_reads) r_end = p.n_reads;
@@ -365,8 +379,8 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           wave_base = __builtin_amdgcn_readfirstlane(wave_base);
           if (reach) {
             const uint32_t slot_i = wave_base + (uint32_t)__builtin_popcountll(vote & ((1ull << lane_id) - 1ull));
-            // ADAPT (single tile, len <= 576): the read's index within the pass rides in the high half
-            lds_list[slot_i] = make_uint2((uint32_t)(o0 - base_al), ADAPT ? (len | (i << 16)) : len);
+            lds_list[slot_i] = make_uint2((uint32_t)(o0 - base_al), len);
+            if (ADAPT) lds_ridx[slot_i] = i;   // first_hit[] is indexed by the read, not by the list slot
           }
         }
         __syncthreads();
@@ -392,8 +406,8 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           } else {
             const uint2 e = lds_list[in_list ? rel : 0u];
             off = e.x + cpos;
-            len = ADAPT ? (e.y & 0xFFFFu) : e.y;
-            ridx[u] = pass + (e.y >> 16);
+            len = e.y;
+            ridx[u] = ADAPT ? pass + lds_ridx[in_list ? rel : 0u] : 0u;
           }
           // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
           // compute codes like their originals but count nothing

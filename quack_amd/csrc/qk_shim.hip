@@ -152,7 +152,7 @@ int grow_table(qk_accum *a, uint64_t need, bool exact = false) {
 struct Plan {
   uint32_t n_tiles, tile_pos, ch, rw;
   uint64_t reads_per_slice, n_slices, n_blocks;
-  uint32_t bucket_log2;
+  uint32_t bucket_log2, halo;
   bool fused_adapters, dynamic;
 };
 constexpr unsigned kQueueRing = 16;      // launches that may be in flight
@@ -177,19 +177,19 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
     cap = 512;
     n_tiles = (max_len + cap - 1) / cap;
   }
-  pl->fused_adapters = a->adapters && n_tiles == 1 && !getenv("QUACK_HIP_UNFUSED_ADAPTERS");
+  pl->fused_adapters = a->adapters && !getenv("QUACK_HIP_UNFUSED_ADAPTERS");
   const uint32_t lanes = pl->fused_adapters ? T / 64 * 62 : T;   // two feeder lanes per wave when fused
-  if (cap / 8 > lanes) {
-    cap = lanes * 8;
+  if (cap / 8 + 2 > lanes) {
+    cap = (lanes - 2) * 8;
     n_tiles = (max_len + cap - 1) / cap;
-    if (n_tiles > 1) pl->fused_adapters = false;
   }
   uint32_t tile_pos = (uint32_t)round_up((max_len + n_tiles - 1) / n_tiles, 8);
   if (tile_pos == 0) tile_pos = 8;
   pl->n_tiles = n_tiles;
   pl->tile_pos = tile_pos;
   pl->ch = tile_pos / 8;
-  pl->rw = (pl->fused_adapters ? T / 64 * 62 : T) / pl->ch;
+  pl->halo = (pl->fused_adapters && n_tiles > 1) ? 2u : 0u;   // lanes covering the 16 positions before a tile
+  pl->rw = (pl->fused_adapters ? T / 64 * 62 : T) / (pl->ch + pl->halo);
   const uint64_t step = (uint64_t)pl->rw * U;
   pl->bucket_log2 = pl->fused_adapters ? a->bucket_log2 : 0;
   if (pl->bucket_log2 && qk::hist_lds_bytes(pl->ch, true, pl->bucket_log2, ragged) > 160 * 1024) pl->bucket_log2 = 0;
@@ -328,6 +328,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   }
   hp.row_dwords = qk::hist_row_dwords(pl.ch);
   hp.replicas = qk::hist_replicas(pl.ch);
+  hp.halo = pl.halo;
   hp.no_adapters = a->adapters ? 0 : 1;
 
   TimedLaunch tl{};

@@ -87,6 +87,42 @@ def test_adapters_ragged_and_long():
                     ob.accumulate_batch(seq, qual, off, kmers=k))
 
 
+@pytest.mark.parametrize("shape", ["fixed300", "ragged150", "ragged_long", "fixed_long"])
+def test_fused_and_separate_adapter_paths_agree(shape, monkeypatch):
+    """the adapter scan fused into the histogram pass (default) and the separate
+    scan kernels (QUACK_HIP_UNFUSED_ADAPTERS=1) are two implementations of
+    quack.c:206-217; both must equal the oracle"""
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    bits = ob.kmers_to_bitset(k)
+    rng = np.random.default_rng(8)
+    if shape == "fixed300":
+        seq, qual = synth.fixed(8000, 300, seed=81)
+        seq = synth.splice_adapters(seq, 300, ads, seed=82)
+        off, L = None, 300
+    elif shape == "fixed_long":
+        seq, qual = synth.fixed(300, 3000, seed=83)
+        seq = synth.splice_adapters(seq, 3000, ads, seed=84, fraction=0.8)
+        off, L = None, 3000
+    else:
+        lo, hi, n = (1, 150, 20000) if shape == "ragged150" else (500, 9000, 600)
+        seq, qual, off = synth.ragged(n, lo, hi, seed=85)
+        L = 0
+        for r in rng.integers(0, n, n // 2):          # adapters anywhere, also across tile seams
+            a, b = int(off[r]), int(off[r + 1])
+            ad = np.frombuffer(ads[int(rng.integers(0, len(ads)))], np.uint8)
+            at = a + int(rng.integers(0, max(1, b - a)))
+            m = min(len(ad), b - at)
+            seq[at:at + m] = ad[:m]
+    want = ob.accumulate_batch(seq, qual, off, read_len=L, kmers=k)
+    assert_same(hip_table(seq, qual, off, read_len=L, kmers_bits=bits), want)
+    monkeypatch.setenv("QUACK_HIP_UNFUSED_ADAPTERS", "1")
+    assert_same(hip_table(seq, qual, off, read_len=L, kmers_bits=bits), want)
+    monkeypatch.setenv("QUACK_HIP_TILE", "64")             # many tiles, halo lanes at every seam
+    monkeypatch.delenv("QUACK_HIP_UNFUSED_ADAPTERS")
+    assert_same(hip_table(seq, qual, off, read_len=L, kmers_bits=bits), want)
+
+
 def test_adapter_hit_positions_edge_cases():
     """first window un-inserted, hit in the seed window, hit ending on the last
     base (not counted), l == 10, l < 10 — SURVEY §8a rows a6/a7"""
