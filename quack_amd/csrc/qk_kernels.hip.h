@@ -493,7 +493,22 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
             // window ending at owned position j = bits [2*(7-j), 2*(7-j)+20) of
             // {prev2&3, plo}; the filter is keyed by the window's low 18 bits
             uint32_t hits = 0;
-#ifndef QK_ABLATE_NO_FILTER
+#if defined(QK_ABLATE_PROBE_VALU_ONLY)   /* the probes' VALU work without the LDS reads */
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int sh = 2 * (7 - j);
+              const uint32_t byte = __builtin_amdgcn_ubfe(plo, sh + 3, kFusedFilterLog2 - 3) * 0x9E3779B1u >> 30;
+              hits |= __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(plo, sh, 3), 1) << j;
+            }
+            hits = hits == 0xFFu ? 1u : 0u;
+#elif defined(QK_ABLATE_PROBE_LDS_ONLY)  /* the LDS reads without the bit tests */
+            {
+              uint32_t x = 0;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) x += filt8[__builtin_amdgcn_ubfe(plo, 2 * (7 - j) + 3, kFusedFilterLog2 - 3)];
+              hits = x == 0x7F7u ? 1u : 0u;
+            }
+#elif !defined(QK_ABLATE_NO_FILTER)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const int sh = 2 * (7 - j);
