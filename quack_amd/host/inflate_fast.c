@@ -217,7 +217,7 @@ static void align_to_byte(qkh_inflate *z) {
   z->bitcnt = 0;
 }
 
-static int read_block_header(qkh_inflate *z) {
+int qkh_read_block_header(qkh_inflate *z) {
   refill_slow(z);
   z->final_block = (int)take_bits(z, 1);
   uint32_t type = take_bits(z, 2);
@@ -294,206 +294,75 @@ static int read_block_header(qkh_inflate *z) {
 /* ------------------------------------------------------------------- API */
 void qkh_inflate_init(qkh_inflate *z, const uint8_t *data, size_t len) {
   memset(z, 0, sizeof *z);
-  z->in = data;
+  z->in = z->base = data;
   z->in_end = data + len;
   z->state = QKH_Z_MEMBER;
 }
 
-/* copy `len` (3..258) bytes from `dist` back; regions may overlap (dist < len).
- * May write up to 15 bytes past dst+len (the fast loop keeps that slack). */
-static inline void copy_match(uint8_t *dst, size_t dist, size_t len) {
-  const uint8_t *src = dst - dist;
-  if (dist >= 8) {
-    /* most FASTQ matches are short: two unconditional 8-byte moves cover <= 16 */
-    memcpy(dst, src, 8);
-    memcpy(dst + 8, src + 8, 8);
-    if (len > 16) {
-      uint8_t *end = dst + len;
-      dst += 16;
-      src += 16;
-      do {
-        memcpy(dst, src, 8);
-        dst += 8;
-        src += 8;
-      } while (dst < end);
-    }
-  } else if (dist == 1) {
-    memset(dst, *src, len);   /* runs (quality plateaus) */
-  } else {
-    for (size_t i = 0; i < len; i++) dst[i] = src[i];
+void qkh_inflate_init_at(qkh_inflate *z, const uint8_t *data, size_t len, uint64_t bit, size_t member_out,
+                         unsigned members, int base_unknown) {
+  qkh_inflate_init(z, data, len);
+  z->in = data + (bit >> 3);
+  if (bit & 7) {
+    refill_slow(z);
+    DROP(z, bit & 7);
   }
+  z->state = QKH_Z_BLOCK;
+  z->member_out = member_out;
+  z->members = members;
+  z->base_unknown = base_unknown;
 }
 
-long qkh_inflate_read(qkh_inflate *z, uint8_t *out, size_t cap, size_t history) {
-  uint8_t *o = out, *const o_end = out + cap;
-  uint8_t *mark = out;   /* output already added to member_out */
-#define ACCOUNT() (z->member_out += (size_t)(o - mark), mark = o)
-  if (z->state == QKH_Z_DONE || z->state == QKH_Z_ERROR) return z->state == QKH_Z_DONE ? 0 : -1;
-  for (;;) {
-    switch (z->state) {
-      case QKH_Z_MEMBER:
-        if (z->in >= z->in_end) {
-          z->state = QKH_Z_DONE;
-          return (long)(o - out);
-        }
-        if (read_gzip_header(z)) {
-          /* trailing garbage after at least one member ends the stream (zlib
-           * behaves the same); garbage instead of a first member is an error */
-          z->state = z->members ? QKH_Z_DONE : QKH_Z_ERROR;
-          return (z->state == QKH_Z_DONE || o > out) ? (long)(o - out) : -1;
-        }
-        z->state = QKH_Z_BLOCK;
-        break;
-      case QKH_Z_BLOCK:
-        if (read_block_header(z) || overran(z)) goto fail;
-        break;
-      case QKH_Z_STORED: {
-        size_t n = z->stored_left, room = (size_t)(o_end - o), avail = (size_t)(z->in_end - z->in);
-        if (n > room) n = room;
-        if (n > avail) goto fail;
-        memcpy(o, z->in, n);
-        o += n;
-        z->in += n;
-        z->stored_left -= (uint32_t)n;
-        if (z->stored_left) goto out_full;
-        z->state = z->final_block ? QKH_Z_TRAILER : QKH_Z_BLOCK;
-        break;
-      }
-      case QKH_Z_CODES: {
-        const uint32_t *lt = z->litlen, *dt = z->dist;
-        /* a match cut by the end of the previous output block */
-        if (z->pend_len) {
-          size_t n = z->pend_len, room = (size_t)(o_end - o);
-          if (n > room) n = room;
-          for (size_t i = 0; i < n; i++) o[i] = o[(ptrdiff_t)i - (ptrdiff_t)z->pend_dist];
-          o += n;
-          z->pend_len -= (uint32_t)n;
-          if (z->pend_len) goto out_full;
-        }
-        for (;;) {
-          /* fast loop: >= 8 input bytes for the refill, room for a longest
-           * match plus the copy's overshoot */
-          while (z->in_end - z->in >= NEED_INPUT_SLACK && o_end - o >= 258 + 32) {
-            uint32_t e;
-            z->bitbuf |= load64(z->in) << z->bitcnt;
-            z->in += (63 - z->bitcnt) >> 3;
-            z->bitcnt |= 56;
-            e = lt[PEEK(z, LITLEN_BITS)];
-            if (__builtin_expect(E_KIND(e) == K_LIT, 1)) {
-              /* literal run: primary-table literals take <= 11 bits each, so
-               * five of them fit in the >= 56 bits of one refill */
-              DROP(z, E_LEN(e));
-              *o++ = (uint8_t)E_VAL(e);
-              e = lt[PEEK(z, LITLEN_BITS)];
-              if (E_KIND(e) == K_LIT) {
-                DROP(z, E_LEN(e));
-                *o++ = (uint8_t)E_VAL(e);
-                e = lt[PEEK(z, LITLEN_BITS)];
-                if (E_KIND(e) == K_LIT) {
-                  DROP(z, E_LEN(e));
-                  *o++ = (uint8_t)E_VAL(e);
-                  e = lt[PEEK(z, LITLEN_BITS)];
-                  if (E_KIND(e) == K_LIT) {
-                    DROP(z, E_LEN(e));
-                    *o++ = (uint8_t)E_VAL(e);
-                    e = lt[PEEK(z, LITLEN_BITS)];
-                    if (E_KIND(e) == K_LIT) {
-                      DROP(z, E_LEN(e));
-                      *o++ = (uint8_t)E_VAL(e);
-                    }
-                  }
-                }
-              }
-              continue;
-            }
-            if (E_KIND(e) == K_SUB) {
-              DROP(z, LITLEN_BITS);
-              e = lt[E_VAL(e) + PEEK(z, E_EXTRA(e))];
-              if (E_KIND(e) == K_LIT) {
-                DROP(z, E_LEN(e));
-                *o++ = (uint8_t)E_VAL(e);
-                continue;
-              }
-            }
-            DROP(z, E_LEN(e));
-            if (E_KIND(e) == K_BASE) {
-              size_t len = E_VAL(e) + PEEK(z, E_EXTRA(e)), dist;
-              uint32_t d;
-              DROP(z, E_EXTRA(e));
-              d = decode_sym(z, dt, DIST_BITS);
-              if (E_KIND(d) != K_BASE) goto fail;
-              dist = E_VAL(d) + PEEK(z, E_EXTRA(d));
-              DROP(z, E_EXTRA(d));
-              if (dist > (size_t)(o - out) + history) goto fail;
-              copy_match(o, dist, len);
-              o += len;
-              continue;
-            }
-            if (E_KIND(e) == K_END) goto block_done;
-            goto fail;
-          }
-          /* careful step: one symbol with every bound checked */
-          {
-            uint32_t e;
-            if (o == o_end) goto out_full;
-            refill_slow(z);
-            e = decode_sym(z, lt, LITLEN_BITS);
-            if (overran(z)) goto fail;
-            if (E_KIND(e) == K_LIT) {
-              *o++ = (uint8_t)E_VAL(e);
-            } else if (E_KIND(e) == K_BASE) {
-              size_t len = E_VAL(e) + PEEK(z, E_EXTRA(e)), dist, n, room;
-              uint32_t d;
-              DROP(z, E_EXTRA(e));
-              refill_slow(z);
-              d = decode_sym(z, dt, DIST_BITS);
-              if (E_KIND(d) != K_BASE) goto fail;
-              dist = E_VAL(d) + PEEK(z, E_EXTRA(d));
-              DROP(z, E_EXTRA(d));
-              if (overran(z)) goto fail;
-              if (dist > (size_t)(o - out) + history) goto fail;
-              room = (size_t)(o_end - o);
-              n = len < room ? len : room;
-              for (size_t i = 0; i < n; i++) o[i] = o[(ptrdiff_t)i - (ptrdiff_t)dist];
-              o += n;
-              if (n < len) {
-                z->pend_len = (uint32_t)(len - n);
-                z->pend_dist = (uint32_t)dist;
-                goto out_full;
-              }
-            } else if (E_KIND(e) == K_END) {
-              goto block_done;
-            } else {
-              goto fail;
-            }
-          }
-        }
-      block_done:
-        z->state = z->final_block ? QKH_Z_TRAILER : QKH_Z_BLOCK;
-        break;
-      }
-      case QKH_Z_TRAILER: {
-        ACCOUNT();
-        align_to_byte(z);
-        if (z->in > z->in_end || z->in_end - z->in < 8) goto fail;
-        uint32_t isize = z->in[4] | ((uint32_t)z->in[5] << 8) | ((uint32_t)z->in[6] << 16) | ((uint32_t)z->in[7] << 24);
-        if (isize != (uint32_t)z->member_out) goto fail;
-        z->in += 8;
-        z->members++;
-        z->state = QKH_Z_MEMBER;
-        break;
-      }
-      default:
-        goto fail;
+/* Where could a block start?  Only dynamic-Huffman headers are looked for
+ * (anything else carries too little structure to recognise; a slice that
+ * really starts with a stored or fixed block is simply decoded in order by
+ * its predecessor's thread, see pinflate.c).  Cheap tests first: block type,
+ * HLIT/HDIST ranges, a complete code-length code; survivors get the full
+ * header parse, which insists on complete literal/length and distance codes. */
+int64_t qkh_inflate_find_block(const uint8_t *data, size_t len, uint64_t from_bit, uint64_t to_bit,
+                               qkh_inflate *scratch) {
+  static const uint8_t kraft[8] = {0, 64, 32, 16, 8, 4, 2, 1};   /* 2^(7-len) */
+  const uint64_t last = len >= 24 ? (uint64_t)(len - 24) * 8u : 0;   /* keep the unaligned loads inside */
+  if (to_bit > last) to_bit = last;
+  for (uint64_t bit = from_bit; bit < to_bit; bit++) {
+    const uint8_t *p = data + (bit >> 3);
+    const unsigned sh = (unsigned)(bit & 7);
+    const uint64_t w = load64(p) >> sh;              /* >= 57 bits */
+    if ((w & 6u) != 4u) continue;                    /* BTYPE == 2 */
+    if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;
+    const unsigned hclen = (unsigned)((w >> 13) & 15u) + 4u;
+    /* code-length code lengths: hclen x 3 bits from bit 17 */
+    uint64_t cl = (w >> 17) | ((load64(p + 7) >> sh) << 39);   /* bits 17.. : 39 from w, rest from p+7 */
+    unsigned sum = 0, nz = 0;
+    for (unsigned i = 0; i < hclen; i++) {
+      const unsigned l = (unsigned)(cl & 7u);
+      cl >>= 3;
+      sum += kraft[l];
+      nz += l != 0;
     }
+    if (sum != 128u && !(nz == 1 && sum == 64u)) continue;
+    qkh_inflate_init_at(scratch, data, len, bit, 0, 1, 1);
+    if (qkh_read_block_header(scratch) == 0 && !overran(scratch)) return (int64_t)bit;
   }
-out_full:
-  ACCOUNT();
-  return (long)(o - out);
-fail:
-  ACCOUNT();
-  z->state = QKH_Z_ERROR;
-  /* what was produced before the error is still delivered, like gzread */
-  return o > out ? (long)(o - out) : -1;
-#undef ACCOUNT
+  return -1;
 }
+
+uint64_t qkh_inflate_bitpos(const qkh_inflate *z) {
+  return (uint64_t)(z->in - z->base) * 8u - (uint64_t)z->bitcnt;
+}
+
+#define OUT_T uint8_t
+#define READ_FN qkh_inflate_read
+#define COPY_FN copy_match8
+#include "inflate_body.inc"
+#undef OUT_T
+#undef READ_FN
+#undef COPY_FN
+
+#define OUT_T uint16_t
+#define READ_FN qkh_inflate_read16
+#define COPY_FN copy_match16
+#include "inflate_body.inc"
+#undef OUT_T
+#undef READ_FN
+#undef COPY_FN

@@ -17,6 +17,14 @@ typedef struct {
   uint32_t pend_len, pend_dist; /* match cut by the end of an output block */
   size_t member_out;            /* bytes produced by the current member (ISIZE check) */
   unsigned members;
+  /* decoding a slice of the stream (pinflate.c) */
+  const uint8_t *base;          /* start of the compressed data: bit positions count from here */
+  uint64_t stop_bit;            /* != 0: stop in front of the first block header at or past this bit */
+  int stopped;                  /* ... which has happened */
+  int base_unknown;             /* started inside a member of unknown length so far */
+  int pend_set;                 /* the first trailer met in that state: its ISIZE and the */
+  uint32_t pend_isize;          /*   bytes this decoder had produced for the member by then */
+  size_t pend_out;
   const uint32_t *litlen, *dist;
   uint32_t fixed_litlen[QKH_LITLEN_TABLE], fixed_dist[QKH_DIST_TABLE];
   uint32_t dyn_litlen[QKH_LITLEN_TABLE], dyn_dist[QKH_DIST_TABLE];
@@ -30,5 +38,23 @@ void qkh_inflate_init(qkh_inflate *z, const uint8_t *data, size_t len);
  * error with nothing produced (bytes produced before an error are returned
  * first, like gzread). */
 long qkh_inflate_read(qkh_inflate *z, uint8_t *out, size_t cap, size_t history);
+
+/* --- decoding from the middle of a stream (speculative parallel inflate) --- */
+/* Start at bit `bit` of `data`, which must be the first bit of a block header
+ * inside a member that has produced `member_out` bytes so far.  With
+ * `base_unknown` the member's earlier length is not known: matches may reach
+ * anywhere into the caller's history and the first ISIZE met is reported in
+ * pend_* instead of checked. */
+void qkh_inflate_init_at(qkh_inflate *z, const uint8_t *data, size_t len, uint64_t bit, size_t member_out,
+                         unsigned members, int base_unknown);
+/* Same decoder over 16-bit elements: values < 256 are bytes, anything else was
+ * copied out of the caller's history (which the caller fills with markers). */
+long qkh_inflate_read16(qkh_inflate *z, uint16_t *out, size_t cap, size_t history);
+uint64_t qkh_inflate_bitpos(const qkh_inflate *z);
+int qkh_read_block_header(qkh_inflate *z);
+/* First bit position in [from_bit, to_bit) where a dynamic-Huffman block header
+ * with complete codes parses, or -1.  `scratch` is clobbered. */
+int64_t qkh_inflate_find_block(const uint8_t *data, size_t len, uint64_t from_bit, uint64_t to_bit,
+                               qkh_inflate *scratch);
 
 #endif

@@ -1,0 +1,362 @@
+/*
+ * pinflate.c — one ordinary gzip stream, inflated by several threads.
+ *
+ * Most FASTQ arrives as plain `gzip` output: one DEFLATE stream whose every
+ * block may refer to the 32 KiB before it, which is why zlib (and the
+ * reference, quack.c:187-193) decode it on one core.  Here the compressed file
+ * is cut into slices of equal compressed size and every slice is decoded
+ * *speculatively* before its predecessor has finished:
+ *
+ *   find    the first position in the slice where a dynamic-Huffman block
+ *           header parses (qkh_inflate_find_block);
+ *   decode  from there into 16-bit elements: the 32 KiB in front of the slice's
+ *           output are filled with markers 0x8000|i ("byte i of the unknown
+ *           window"), so matches that reach into the unknown simply copy
+ *           markers around (qkh_inflate_read16) — until the first block
+ *           boundary at or past the next slice's nominal start;
+ *   chain   strictly in slice order, and cheap: a slice's speculation is kept
+ *           only if it began exactly where its predecessor's decoding ended
+ *           (otherwise the start was not a real block boundary, or a stored /
+ *           fixed block was skipped).  Then the predecessor's last 32 KiB
+ *           resolve this slice's last 32 KiB, which releases the next slice;
+ *   resolve markers -> bytes for the whole slice (a 64 KiB table lookup per
+ *           element), in parallel with everybody else.
+ *
+ * A slice whose speculation cannot be kept — no header found, a decode error, a
+ * start that does not line up, a member boundary closer than 32 KiB — is
+ * decoded again, in order, by the ordinary byte decoder from the exact bit
+ * where its predecessor stopped.  So the bytes delivered, and the byte at which
+ * a damaged file stops, are those of the serial decoder by construction; the
+ * speculation only ever saves time.  (The idea is that of pugz / rapidgzip;
+ * the code is not.)
+ */
+#include "pinflate.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "inflate_fast.h"
+
+enum { WIN = 32768, MAX_THREADS = 32 };
+
+typedef struct {
+  uint16_t *b16;   /* WIN markers + speculative output */
+  size_t cap16;    /* output elements that fit */
+  uint8_t *b8;     /* WIN bytes of history + output */
+  size_t cap8;
+  size_t len;      /* output bytes of the slice, at b8 + WIN */
+  int ready;
+} pslot;
+
+struct qkh_pinflate {
+  const uint8_t *in;
+  size_t in_len, slice;
+  unsigned n_slices, n_slots;
+  pslot *slots;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  unsigned next_slice;   /* next slice without a worker */
+  unsigned tail;         /* slices consumed */
+  int holding, stop, failed;
+  /* the chain: state of the stream in front of slice `chain_next` */
+  unsigned chain_next;
+  uint64_t chain_bit;
+  uint8_t chain_win[WIN];
+  size_t chain_win_len, chain_member_out;
+  unsigned chain_members;
+  int chain_end;         /* the stream ended (or broke) inside an earlier slice */
+  int n_threads;
+  pthread_t threads[MAX_THREADS];
+  /* statistics (tests, QUACK_VERBOSE) */
+  unsigned kept, redone;
+};
+
+static int grow16(pslot *s, size_t need) {
+  if (need <= s->cap16) return 0;
+  size_t cap = s->cap16 + s->cap16 / 2;
+  if (cap < need) cap = need;
+  uint16_t *nb = realloc(s->b16, (WIN + cap + 64) * sizeof *nb);
+  if (!nb) return -1;
+  if (!s->b16)
+    for (unsigned i = 0; i < WIN; i++) nb[i] = (uint16_t)(0x8000u | i);
+  s->b16 = nb;
+  s->cap16 = cap;
+  return 0;
+}
+
+static int grow8(pslot *s, size_t need) {
+  if (need <= s->cap8) return 0;
+  size_t cap = s->cap8 + s->cap8 / 2;
+  if (cap < need) cap = need;
+  uint8_t *nb = realloc(s->b8, WIN + cap + 64);
+  if (!nb) return -1;
+  s->b8 = nb;
+  s->cap8 = cap;
+  return 0;
+}
+
+/* bit where slice k nominally begins */
+static uint64_t slice_bit(const qkh_pinflate *p, unsigned k) { return (uint64_t)k * p->slice * 8u; }
+
+typedef struct {
+  int found, ok, end;
+  uint64_t start_bit, end_bit;
+  size_t n;
+} spec_result;
+
+static void speculate(qkh_pinflate *p, unsigned k, pslot *s, qkh_inflate *z, spec_result *r) {
+  memset(r, 0, sizeof *r);
+  const uint64_t to = k + 1 < p->n_slices ? slice_bit(p, k + 1) : (uint64_t)p->in_len * 8u;
+  const int64_t at = qkh_inflate_find_block(p->in, p->in_len, slice_bit(p, k), to, z);
+  if (at < 0) return;
+  r->found = 1;
+  r->start_bit = (uint64_t)at;
+  qkh_inflate_init_at(z, p->in, p->in_len, (uint64_t)at, 0, 0, 1);
+  z->stop_bit = k + 1 < p->n_slices ? slice_bit(p, k + 1) : 0;
+  if (grow16(s, p->slice * 5)) return;
+  size_t n = 0;
+  for (;;) {
+    if (n == s->cap16 && grow16(s, n + 1)) return;
+    long got = qkh_inflate_read16(z, s->b16 + WIN + n, s->cap16 - n, WIN + n);
+    if (got > 0) n += (size_t)got;
+    if (z->state == QKH_Z_ERROR) return;   /* garbage, or a damaged file: decided in order */
+    if (z->stopped || z->state == QKH_Z_DONE) break;
+    if (got <= 0) return;
+  }
+  r->ok = 1;
+  r->end = z->state == QKH_Z_DONE;
+  r->end_bit = qkh_inflate_bitpos(z);
+  r->n = n;
+}
+
+static __attribute__((noinline)) void resolve(const uint16_t *src, uint8_t *dst, size_t n, const uint8_t *lut) {
+  size_t i = 0;
+  for (; i + 4 <= n; i += 4) {
+    dst[i] = lut[src[i]];
+    dst[i + 1] = lut[src[i + 1]];
+    dst[i + 2] = lut[src[i + 2]];
+    dst[i + 3] = lut[src[i + 3]];
+  }
+  for (; i < n; i++) dst[i] = lut[src[i]];
+}
+
+typedef struct {
+  qkh_pinflate *p;
+  qkh_inflate *z;
+  uint8_t *lut;   /* 65536: identity below 256, the previous window from 0x8000 */
+} worker;
+
+static void *worker_main(void *arg) {
+  worker *w = arg;
+  qkh_pinflate *p = w->p;
+  qkh_inflate *z = w->z;
+  uint8_t *lut = w->lut;
+  for (unsigned i = 0; i < 256; i++) lut[i] = (uint8_t)i;
+  for (;;) {
+    unsigned k;
+    pslot *s;
+    spec_result sp;
+    pthread_mutex_lock(&p->mu);
+    while (!p->stop && !p->chain_end && p->next_slice < p->n_slices && p->next_slice - p->tail >= p->n_slots)
+      pthread_cond_wait(&p->cv, &p->mu);
+    if (p->stop || p->chain_end || p->next_slice >= p->n_slices) {
+      pthread_mutex_unlock(&p->mu);
+      break;
+    }
+    k = p->next_slice++;
+    s = &p->slots[k % p->n_slots];
+    s->ready = 0;
+    s->len = 0;
+    pthread_mutex_unlock(&p->mu);
+
+    memset(&sp, 0, sizeof sp);
+    if (k > 0) speculate(p, k, s, z, &sp);
+
+    /* ---- my turn in the chain */
+    pthread_mutex_lock(&p->mu);
+    while (!p->stop && p->chain_next != k) pthread_cond_wait(&p->cv, &p->mu);
+    if (p->stop) {
+      pthread_mutex_unlock(&p->mu);
+      break;
+    }
+    /* chain_* belong to this thread until it advances chain_next */
+    const int ended = p->chain_end;
+    pthread_mutex_unlock(&p->mu);
+
+    size_t n = 0, member_out = 0;
+    unsigned members = 0;
+    uint64_t end_bit = 0;
+    int end = ended, failed = 0, keep = 0;
+    uint8_t new_win[WIN];
+    size_t new_win_len = 0;
+
+    if (!ended) {
+      keep = k > 0 && sp.found && sp.ok && sp.start_bit == p->chain_bit && p->chain_member_out >= WIN &&
+             (!z->pend_set || (uint32_t)(p->chain_member_out + z->pend_out) == z->pend_isize) &&
+             grow8(s, sp.n) == 0;
+      if (keep) {
+        n = sp.n;
+        memcpy(lut + 0x8000, p->chain_win, WIN);
+        if (n >= WIN) {
+          resolve(s->b16 + WIN + n - WIN, new_win, WIN, lut);
+        } else {
+          memcpy(new_win, p->chain_win + n, WIN - n);
+          resolve(s->b16 + WIN, new_win + WIN - n, n, lut);
+        }
+        new_win_len = WIN;
+        member_out = z->base_unknown ? p->chain_member_out + n : z->member_out;
+        members = p->chain_members + z->members;
+        end_bit = sp.end_bit;
+        end = sp.end;
+      } else {
+        /* in order, from the exact bit the previous slice stopped at */
+        if (k == 0) qkh_inflate_init(z, p->in, p->in_len);
+        else qkh_inflate_init_at(z, p->in, p->in_len, p->chain_bit, p->chain_member_out, p->chain_members, 0);
+        z->stop_bit = k + 1 < p->n_slices ? slice_bit(p, k + 1) : 0;
+        if (grow8(s, p->slice * 5)) failed = 1;
+        else memcpy(s->b8 + WIN - p->chain_win_len, p->chain_win, p->chain_win_len);
+        while (!failed) {
+          if (n == s->cap8 && grow8(s, n + 1)) {
+            failed = 1;
+            break;
+          }
+          long got = qkh_inflate_read(z, s->b8 + WIN + n, s->cap8 - n, p->chain_win_len + n);
+          if (got > 0) n += (size_t)got;
+          if (z->stopped || z->state == QKH_Z_DONE || z->state == QKH_Z_ERROR || got <= 0) break;
+        }
+        end = failed || !z->stopped;   /* finished, or broken at this byte: nothing follows */
+        end_bit = qkh_inflate_bitpos(z);
+        member_out = z->member_out;
+        members = z->members;
+        if (!failed) {
+          new_win_len = p->chain_win_len + n < WIN ? p->chain_win_len + n : WIN;
+          memcpy(new_win, s->b8 + WIN + n - new_win_len, new_win_len);
+        }
+      }
+    }
+
+    pthread_mutex_lock(&p->mu);
+    if (!ended) {
+      memcpy(p->chain_win, new_win, new_win_len);
+      p->chain_win_len = new_win_len;
+      p->chain_bit = end_bit;
+      p->chain_member_out = member_out;
+      p->chain_members = members;
+      p->chain_end = end;
+      if (failed) p->failed = 1;
+      if (keep) p->kept++;
+      else p->redone++;
+    }
+    p->chain_next = k + 1;
+    if (!keep) {
+      s->len = failed ? 0 : n;
+      s->ready = 1;
+    }
+    pthread_cond_broadcast(&p->cv);
+    pthread_mutex_unlock(&p->mu);
+
+    if (keep) {
+      /* the bulk of the work, off the chain: lut still holds the previous window */
+      resolve(s->b16 + WIN, s->b8 + WIN, n, lut);
+      pthread_mutex_lock(&p->mu);
+      s->len = n;
+      s->ready = 1;
+      pthread_cond_broadcast(&p->cv);
+      pthread_mutex_unlock(&p->mu);
+    }
+  }
+  free(w->z);
+  free(w->lut);
+  free(w);
+  return NULL;
+}
+
+qkh_pinflate *qkh_pinflate_open(const uint8_t *data, size_t len, int threads, size_t slice_bytes) {
+  qkh_pinflate *p = calloc(1, sizeof *p);
+  if (!p) return NULL;
+  if (threads < 1) threads = 1;
+  if (threads > MAX_THREADS) threads = MAX_THREADS;
+  if (slice_bytes < 4096) slice_bytes = 4096;
+  p->in = data;
+  p->in_len = len;
+  p->slice = slice_bytes;
+  p->n_slices = (unsigned)((len + slice_bytes - 1) / slice_bytes);
+  if (!p->n_slices) p->n_slices = 1;
+  p->n_slots = (unsigned)threads + 4;
+  p->slots = calloc(p->n_slots, sizeof *p->slots);
+  pthread_mutex_init(&p->mu, NULL);
+  pthread_cond_init(&p->cv, NULL);
+  if (!p->slots) goto fail;
+  for (int i = 0; i < threads; i++) {
+    worker *w = calloc(1, sizeof *w);
+    if (w) {
+      w->p = p;
+      w->z = malloc(sizeof *w->z);
+      w->lut = calloc(1, 65536);
+    }
+    if (!w || !w->z || !w->lut || pthread_create(&p->threads[p->n_threads], NULL, worker_main, w)) {
+      if (w) {
+        free(w->z);
+        free(w->lut);
+      }
+      free(w);
+      break;
+    }
+    p->n_threads++;
+  }
+  if (!p->n_threads) goto fail;
+  return p;
+fail:
+  qkh_pinflate_close(p);
+  return NULL;
+}
+
+int qkh_pinflate_next(qkh_pinflate *p, const uint8_t **data, size_t *len) {
+  for (;;) {
+    pslot *s;
+    pthread_mutex_lock(&p->mu);
+    if (p->holding) {
+      p->holding = 0;
+      p->tail++;
+      pthread_cond_broadcast(&p->cv);
+    }
+    for (;;) {
+      if (p->tail < p->next_slice && p->slots[p->tail % p->n_slots].ready) break;
+      if (p->tail == p->n_slices || (p->chain_end && p->tail == p->next_slice) || p->stop) {
+        pthread_mutex_unlock(&p->mu);
+        return 0;
+      }
+      pthread_cond_wait(&p->cv, &p->mu);
+    }
+    s = &p->slots[p->tail % p->n_slots];
+    *data = s->b8 + WIN;
+    *len = s->len;
+    p->holding = 1;
+    pthread_mutex_unlock(&p->mu);
+    if (*len) return 1;
+  }
+}
+
+void qkh_pinflate_stats(const qkh_pinflate *p, unsigned *kept, unsigned *redone) {
+  *kept = p->kept;
+  *redone = p->redone;
+}
+
+void qkh_pinflate_close(qkh_pinflate *p) {
+  if (!p) return;
+  pthread_mutex_lock(&p->mu);
+  p->stop = 1;
+  pthread_cond_broadcast(&p->cv);
+  pthread_mutex_unlock(&p->mu);
+  for (int i = 0; i < p->n_threads; i++) pthread_join(p->threads[i], NULL);
+  pthread_mutex_destroy(&p->mu);
+  pthread_cond_destroy(&p->cv);
+  if (p->slots)
+    for (unsigned i = 0; i < p->n_slots; i++) {
+      free(p->slots[i].b16);
+      free(p->slots[i].b8);
+    }
+  free(p->slots);
+  free(p);
+}

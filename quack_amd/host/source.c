@@ -3,16 +3,19 @@
  *
  * Decompressed bytes arrive in 4 MiB blocks, in stream order, from producer
  * threads, so that inflate (78 % of the reference's wall time)
- * overlaps parsing, the PCIe copies and the kernels.  Four producers:
+ * overlaps parsing, the PCIe copies and the kernels.  Five producers:
  *
  *   bgzf     a BGZF file (gzip members of <= 64 KiB that carry their own size
  *            in a "BC" extra field — bgzip, htslib): a dispatcher walks the
  *            member headers and a pool of workers decodes runs of members in
  *            parallel, each straight into its ring block;
- *   inflate  any other regular gzip file is memory-mapped and decoded by one
- *            thread with inflate_fast.c (~1.65x zlib on FASTQ); every block
- *            carries the previous 32 KiB of output in front of its data, which
- *            is all DEFLATE can refer back to;
+ *   pgzip    any other regular gzip file is memory-mapped and decoded by a
+ *            pool of threads that start speculatively in the middle of the
+ *            stream (pinflate.c);
+ *   inflate  the same with one thread (small files, QUACK_THREADS=1,
+ *            QUACK_NO_PGZIP=1): inflate_fast.c, ~1.65x zlib on FASTQ; every
+ *            block carries the previous 32 KiB of output in front of its data,
+ *            which is all DEFLATE can refer back to;
  *   zlib     gzip from a pipe, or QUACK_ZLIB=1: zlib's gzread, like the
  *            reference (quack.c:160,187);
  *   plain    a regular file that is not gzip: read(2).
@@ -33,6 +36,7 @@
 #include <zlib.h>
 
 #include "inflate_fast.h"
+#include "pinflate.h"
 
 enum { BLOCK_BYTES = 4 << 20, HIST = 32768, SERIAL_RING = 4, MAX_WORKERS = 32 };
 
@@ -66,6 +70,8 @@ struct qkh_source {
   int fd;
   const uint8_t *map;
   size_t map_len;
+  /* parallel inflate of one gzip stream: has its own slots and threads */
+  qkh_pinflate *pz;
   /* serial inflate_fast */
   qkh_inflate *zf;
   uint8_t *hist;
@@ -265,6 +271,11 @@ static int n_cpus(void) {
   return (int)n;
 }
 
+static size_t pgzip_slice(void) {
+  const char *e = getenv("QUACK_PGZIP_CHUNK_KB");
+  return e && atoi(e) > 0 ? (size_t)atoi(e) << 10 : (size_t)1 << 20;
+}
+
 qkh_source *qkh_source_open(const char *path) {
   qkh_source *s = calloc(1, sizeof *s);
   struct stat st;
@@ -303,6 +314,11 @@ qkh_source *qkh_source_open(const char *path) {
         if (bgzf_member_size(s->map, s->map + s->map_len) && !getenv("QUACK_NO_BGZF")) {
           workers = n_cpus();
           snprintf(s->kind, sizeof s->kind, "bgzf x%d", workers);
+        } else if (n_cpus() > 1 && !getenv("QUACK_NO_PGZIP") && s->map_len >= 2 * pgzip_slice()) {
+          s->pz = qkh_pinflate_open(s->map, s->map_len, n_cpus(), pgzip_slice());
+          if (!s->pz) goto fail;
+          snprintf(s->kind, sizeof s->kind, "pgzip x%d", n_cpus());
+          return s;
         } else {
           s->zf = malloc(sizeof *s->zf);
           s->hist = malloc(HIST);
@@ -353,6 +369,7 @@ fail:
 }
 
 int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len) {
+  if (s->pz) return qkh_pinflate_next(s->pz, data, len);
   for (;;) {
     block *b;
     pthread_mutex_lock(&s->mu);
@@ -390,6 +407,12 @@ void qkh_source_close(qkh_source *s) {
   pthread_cond_broadcast(&s->filled);
   pthread_mutex_unlock(&s->mu);
   for (int i = 0; i < s->n_threads; i++) pthread_join(s->threads[i], NULL);
+  if (s->pz && getenv("QUACK_VERBOSE")) {
+    unsigned kept, redone;
+    qkh_pinflate_stats(s->pz, &kept, &redone);
+    fprintf(stderr, "[quack] %s: %u slices decoded speculatively, %u in order\n", s->kind, kept, redone);
+  }
+  qkh_pinflate_close(s->pz);
   pthread_mutex_destroy(&s->mu);
   pthread_cond_destroy(&s->space);
   pthread_cond_destroy(&s->filled);

@@ -192,6 +192,15 @@ int main(int argc, char **argv) {
     size_t n = make_text(text, 1 << 20);
     for (int gz = 0; gz < 3; gz++) {
       write_file(path, text, n, gz);
+      /* ordinary gzip: every other round through the multi-threaded decoder,
+       * with slices small enough for these files */
+      if (gz == 1 && (it & 1)) {
+        setenv("QUACK_PGZIP_CHUNK_KB", it % 4 == 1 ? "4" : "23", 1);
+        setenv("QUACK_THREADS", it % 3 ? "3" : "7", 1);
+      } else {
+        unsetenv("QUACK_PGZIP_CHUNK_KB");
+        setenv("QUACK_THREADS", "2", 1);
+      }
       static const size_t caps[4] = {1 << 20, 4096, 1000, 257};
       for (int c = 0; c < 4; c++) {
         int rc = compare(path, caps[c], c == 2 ? 3 : 10000);
@@ -207,6 +216,38 @@ int main(int argc, char **argv) {
     }
   }
   unlink(path);
+  /* large ordinary-gzip files: enough blocks for the speculative decoder of
+   * pinflate.c to keep most of its slices */
+  {
+    const size_t big_cap = 5u << 20;
+    char *big = malloc(big_cap);
+    for (int it = 0; it < iters / 25 + 2; it++) {
+      size_t n = 0;
+      while (n + 200000 < big_cap) n += make_text(big + n, big_cap - n);
+      z_stream zs;
+      memset(&zs, 0, sizeof zs);
+      deflateInit2(&zs, 1 + (int)(rnd() % 9), Z_DEFLATED, 31, 1 + (int)(rnd() % 9), Z_DEFAULT_STRATEGY);
+      size_t cap = deflateBound(&zs, n) + 64;
+      unsigned char *out = malloc(cap);
+      zs.next_in = (unsigned char *)big;
+      zs.avail_in = (uInt)n;
+      zs.next_out = out;
+      zs.avail_out = (uInt)cap;
+      deflate(&zs, Z_FINISH);
+      FILE *f = fopen(path, "wb");
+      fwrite(out, 1, cap - zs.avail_out, f);
+      fclose(f);
+      deflateEnd(&zs);
+      free(out);
+      setenv("QUACK_PGZIP_CHUNK_KB", it & 1 ? "4" : "64", 1);
+      setenv("QUACK_THREADS", it % 3 ? "4" : "2", 1);
+      if (compare(path, 1 << 20, 10000)) {
+        failures++;
+        printf("FAIL big it=%d n=%zu\n", it, n);
+      }
+    }
+    free(big);
+  }
   free(text);
   printf("host_fuzz: %d iterations, %d failures\n", iters, failures);
   return failures != 0;

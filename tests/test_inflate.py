@@ -157,7 +157,8 @@ def test_bgzf_parallel_inflate_gives_the_same_records(tmp_path, monkeypatch, blo
     p_b, p_g = tmp_path / "x.fq.bgz", tmp_path / "x.fq.gz"
     p_b.write_bytes(bgzf(text, block))
     p_g.write_bytes(gz(text))
-    assert source_kind(str(p_b)).startswith("bgzf x") and source_kind(str(p_g)) == "inflate_fast"
+    assert source_kind(str(p_b)).startswith("bgzf x")
+    assert source_kind(str(p_g)) == ("inflate_fast" if threads == "1" else "pgzip x" + threads)
     a, _ = product_tokenize(str(p_b), 1 << 22, 1 << 16)
     b, _ = product_tokenize(str(p_g), 1 << 22, 1 << 16)
     assert len(a) == 30000 and a == b
@@ -181,3 +182,136 @@ def product_tokenize_text(tmp_path, text):
     q = tmp_path / "plain.fq"
     q.write_bytes(text)
     return product_tokenize(str(q))
+
+
+# ------------------------------------------------ ordinary gzip, several threads
+def source_bytes(path):
+    """the whole decompressed stream as the tokenizer would see it"""
+    H = _capi.host()
+    H.qkh_source_open.restype = ctypes.c_void_p
+    H.qkh_source_open.argtypes = [ctypes.c_char_p]
+    H.qkh_source_next.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    H.qkh_source_kind.restype = ctypes.c_char_p
+    H.qkh_source_kind.argtypes = [ctypes.c_void_p]
+    H.qkh_source_close.argtypes = [ctypes.c_void_p]
+    s = H.qkh_source_open(os.fsencode(path))
+    assert s
+    kind = H.qkh_source_kind(s).decode()
+    d, n, out = ctypes.c_void_p(), ctypes.c_size_t(), []
+    while H.qkh_source_next(s, ctypes.byref(d), ctypes.byref(n)):
+        out.append(ctypes.string_at(d.value, n.value))
+    H.qkh_source_close(s)
+    return kind, b"".join(out)
+
+
+def np_fastq(n, length, seed):
+    g = np.random.default_rng(seed)
+    seq = np.frombuffer(b"ACGT", np.uint8)[g.integers(0, 4, (n, length))]
+    # qualities with plateaus, like real instruments: long matches and dist-1 runs
+    q = (33 + np.repeat(g.integers(2, 41, (n, length // 10 + 1)), 10, axis=1)[:, :length]).astype(np.uint8)
+    rows = []
+    for i in range(n):
+        rows.append(b"@read%d some/description\n" % i + seq[i].tobytes() + b"\n+\n" + q[i].tobytes() + b"\n")
+    return b"".join(rows)
+
+
+BIG = {}
+
+
+def big(name):
+    if not BIG:
+        g = np.random.default_rng(5)
+        BIG["fastq"] = np_fastq(20000, 150, 1)                          # 6.7 MB
+        BIG["ragged"] = b"".join(np_fastq(1, int(l), int(l)) for l in g.integers(1, 4000, 1200))
+        BIG["zeros"] = bytes(30 << 20)                                   # ratio ~1000: output buffers must grow
+        BIG["random"] = g.integers(0, 256, 3 << 20, dtype=np.uint8).tobytes()   # stored blocks only
+        BIG["mixed"] = BIG["fastq"][:2 << 20] + BIG["random"][:1 << 20] + BIG["fastq"][2 << 20:4 << 20] + bytes(1 << 20)
+    return BIG[name]
+
+
+@pytest.mark.parametrize("name,level,strategy", [
+    ("fastq", 6, zlib.Z_DEFAULT_STRATEGY), ("fastq", 1, zlib.Z_DEFAULT_STRATEGY), ("fastq", 9, zlib.Z_DEFAULT_STRATEGY),
+    ("fastq", 6, zlib.Z_FIXED), ("fastq", 6, zlib.Z_HUFFMAN_ONLY), ("ragged", 6, zlib.Z_DEFAULT_STRATEGY),
+    ("zeros", 6, zlib.Z_DEFAULT_STRATEGY), ("random", 6, zlib.Z_DEFAULT_STRATEGY), ("mixed", 6, zlib.Z_DEFAULT_STRATEGY),
+    ("mixed", 0, zlib.Z_DEFAULT_STRATEGY)])
+def test_parallel_gzip_delivers_exactly_the_stream(tmp_path, monkeypatch, capfd, name, level, strategy):
+    data = big(name)
+    p = tmp_path / "x.gz"
+    p.write_bytes(gz(data, level, strategy))
+    for threads, chunk_kb in (("3", "16"), ("8", "4"), ("2", "300")):
+        if p.stat().st_size < 2 * int(chunk_kb) * 1024:
+            continue
+        monkeypatch.setenv("QUACK_THREADS", threads)
+        monkeypatch.setenv("QUACK_PGZIP_CHUNK_KB", chunk_kb)
+        monkeypatch.setenv("QUACK_VERBOSE", "1")
+        kind, got = source_bytes(str(p))
+        assert kind == "pgzip x" + threads
+        assert got == data, (name, level, threads, chunk_kb)
+        err = capfd.readouterr().err
+        kept, redone = [int(t) for t in err.replace(",", " ").split() if t.isdigit()][-2:]
+        if name in ("fastq", "ragged") and strategy == zlib.Z_DEFAULT_STRATEGY:
+            # the speculation really is what ran (slices smaller than a DEFLATE
+            # block often hold no block start at all and are redone, empty)
+            assert kept >= (2 * redone if chunk_kb == "300" else 10), err
+        if strategy == zlib.Z_FIXED or name == "random":
+            assert kept == 0, err                  # nothing to recognise: all in order, still right
+
+
+def test_parallel_gzip_members_garbage_and_damage(tmp_path, monkeypatch):
+    """whatever the file, the bytes delivered are those of the one-thread decoder"""
+    monkeypatch.setenv("QUACK_THREADS", "4")
+    monkeypatch.setenv("QUACK_PGZIP_CHUNK_KB", "8")
+    fq = big("fastq")
+    p = tmp_path / "x.gz"
+
+    def both():
+        kind, par = source_bytes(str(p))
+        monkeypatch.setenv("QUACK_NO_PGZIP", "1")
+        kind1, ser = source_bytes(str(p))
+        monkeypatch.delenv("QUACK_NO_PGZIP")
+        assert kind1 == "inflate_fast" and (kind == "pgzip x4" or p.stat().st_size < 16384)
+        return par, ser
+
+    # many members of very different sizes (members shorter than the window too)
+    g = np.random.default_rng(9)
+    cuts = sorted(set([0, len(fq)] + [int(c) for c in g.integers(0, len(fq), 40)] + [100000 + i * 900 for i in range(30)]))
+    members = [gz(fq[a:b], int(g.integers(1, 10))) for a, b in zip(cuts, cuts[1:])]
+    p.write_bytes(b"".join(members))
+    par, ser = both()
+    assert par == fq and ser == fq
+    # trailing garbage after the last member is ignored
+    p.write_bytes(b"".join(members) + b"\0" * 5000 + b"junk")
+    par, ser = both()
+    assert par == fq and ser == fq
+    # truncated and damaged files: a prefix of the truth, the same prefix
+    whole = gz(fq, 6)
+    for cut in (len(whole) // 3, len(whole) - 5, 9000):
+        p.write_bytes(whole[:cut])
+        par, ser = both()
+        assert par == ser and fq.startswith(par) and (cut < 10000 or len(par) > 0)
+    r = random.Random(4)
+    for _ in range(25):
+        c = bytearray(whole)
+        for _ in range(r.randrange(1, 4)):
+            c[r.randrange(20, len(c))] ^= 1 << r.randrange(8)
+        p.write_bytes(bytes(c))
+        par, ser = both()
+        assert par == ser
+    # a wrong ISIZE in the middle of the file stops the stream there
+    m1, m2 = gz(fq[:3 << 20], 6), gz(fq[3 << 20:], 6)
+    bad = bytearray(m1)
+    bad[-2] ^= 0x10
+    p.write_bytes(bytes(bad) + m2)
+    par, ser = both()
+    assert par == ser == fq[:3 << 20]
+
+
+def test_parallel_gzip_through_the_tokenizer(tmp_path, monkeypatch):
+    monkeypatch.setenv("QUACK_THREADS", "5")
+    monkeypatch.setenv("QUACK_PGZIP_CHUNK_KB", "64")
+    text = big("fastq")
+    p = tmp_path / "x.fq.gz"
+    p.write_bytes(gz(text, 6))
+    a, _ = product_tokenize(str(p), 1 << 22, 1 << 16)
+    want, _ = product_tokenize_text(tmp_path, text)
+    assert len(a) == 20000 and a == want
