@@ -92,6 +92,12 @@ struct qk_accum {
   unsigned queue_seq = 0;
   uint32_t *d_hit_scratch = nullptr;  // first-hit buffer for device submits
   uint64_t hit_scratch_reads = 0;
+  // launches of one accumulator run in submission order even when they come
+  // from different streams: they share the queue ring, the first-hit scratch
+  // and the table's flush targets
+  hipEvent_t order_ev = nullptr;
+  hipStream_t order_stream = nullptr;
+  bool order_valid = false;
   // tuning
   int threads = 1024, unroll = 4, tile = 0, wgs_per_cu = 0;   // 0 = automatic
   // timing
@@ -202,8 +208,8 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // Work items = tiles x read slices.  Single tile: one item per resident
   // workgroup.  Several tiles (long reads): reads do not reach the far tiles
   // equally, so the slices are cut ~16x finer than the resident workgroups and
-  // pulled from a device queue in tile-major order; a workgroup flushes its LDS
-  // histogram only when its tile changes.
+  // pulled from per-tile device counters (see hist_kernel: home tiles); a
+  // workgroup flushes its LDS histogram only when its tile changes.
   const uint64_t resident = (uint64_t)a->n_cu * wgs;
   pl->dynamic = n_tiles > 1;
   uint64_t want_items = pl->dynamic ? resident * 16 : resident;
@@ -229,7 +235,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   pl->reads_per_slice = rps;
   pl->n_slices = (n_reads + rps - 1) / rps;
   if (pl->n_slices > 0xFFFFFF00ull) return fail(QK_EINVAL, "too many read slices");
-  pl->n_blocks = pl->dynamic ? std::max<uint64_t>(resident, n_tiles <= resident ? resident : resident) : pl->n_slices;
+  pl->n_blocks = pl->dynamic ? resident : pl->n_slices;   // persistent workgroups when dynamic
   return QK_OK;
 }
 
@@ -299,6 +305,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   Plan pl;
   rc = make_plan(a, n_reads, max_len, d_off != nullptr, &pl);
   if (rc) return rc;
+  if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));
   qk::HistParams hp{};
   hp.seq = d_seq;
   hp.qual = d_qual;
@@ -350,6 +357,9 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     rc = pl.fused_adapters ? qk::launch_adapter_count(hp, a->n_cu, st) : qk::launch_adapter_scan(hp, a->n_cu, st);
     if (rc) return fail(QK_EHIP, "adapter kernels failed: %s", hipGetErrorString((hipError_t)rc));
   }
+  QK_HIP(hipEventRecord(a->order_ev, st));
+  a->order_stream = st;
+  a->order_valid = true;
   a->n_reads += n_reads;
   a->max_len = std::max<uint64_t>(a->max_len, max_len);
   return QK_OK;
@@ -422,8 +432,9 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
     a->unroll = env_int("QUACK_HIP_UNROLL", a->unroll);
     a->tile = env_int("QUACK_HIP_TILE", a->tile);
     a->wgs_per_cu = env_int("QUACK_HIP_WGS_PER_CU", a->wgs_per_cu);
-    if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) {
-      rc = fail(QK_EHIP, "hipStreamCreate failed");
+    if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&a->order_ev, hipEventDisableTiming) != hipSuccess) {
+      rc = fail(QK_EHIP, "hipStreamCreate / hipEventCreate failed");
       break;
     }
     if (kmer_bitset) {
@@ -485,6 +496,7 @@ void qk_accum_destroy(qk_accum *a) {
   if (a->d_kmer_filter) (void)hipFree(a->d_kmer_filter);
   if (a->d_kmer_buckets) (void)hipFree(a->d_kmer_buckets);
   if (a->d_table) (void)hipFree(a->d_table);
+  if (a->order_ev) (void)hipEventDestroy(a->order_ev);
   if (a->stream) (void)hipStreamDestroy(a->stream);
   delete a;
 }
@@ -638,6 +650,7 @@ int qk_accum_submit_device(qk_accum *a, const void *d_seq, const void *d_qual,
       QK_HIP(hipDeviceSynchronize());
       if (a->d_hit_scratch) QK_HIP(hipFree(a->d_hit_scratch));
       a->d_hit_scratch = nullptr;
+      a->hit_scratch_reads = 0;
       QK_HIP(hipMalloc((void **)&a->d_hit_scratch, n_reads * sizeof(uint32_t)));
       a->hit_scratch_reads = n_reads;
     }

@@ -13,6 +13,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "quack_host.h"
 
@@ -28,6 +29,12 @@ static int host_fail(const char *fmt, ...) {
   return -1;
 }
 
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int qkh_accumulate_file(const char *path, const uint32_t *bitset,
                         const int *devices, int n_devices,
                         qk_base_info **bases_out, uint64_t *max_len,
@@ -35,19 +42,24 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
   qk_accum *accs[64];
   qkh_reader *rd = NULL;
   int rc = -1, turn = 0, made = 0;
+  const int verbose = getenv("QUACK_VERBOSE") != NULL;
+  const double t0 = now_s();
+  double t_created, t_first = 0, t_parsed;
   *bases_out = NULL;
   *max_len = *n_reads = 0;
   if (n_devices < 1 || n_devices > 64) return host_fail("bad device count %d", n_devices);
+  /* the producer threads start inflating now, while HIP initialises below */
+  rd = qkh_reader_open(path);
   for (; made < n_devices; made++)
     if (qk_accum_create(&accs[made], devices[made], bitset, 0)) {
       host_fail("device %d: %s", devices[made], qk_last_error());
       goto out;
     }
-  rd = qkh_reader_open(path);
   if (!rd) {
     host_fail("cannot open %s", path);
     goto out;
   }
+  t_created = now_s();
   while (!qkh_reader_done(rd)) {
     uint8_t *seq, *qual;
     uint64_t *offsets, cap_bytes, cap_reads, total = 0;
@@ -58,6 +70,7 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       host_fail("%s", qk_last_error());
       goto out;
     }
+    if (!t_first) t_first = now_s();
     n = qkh_reader_fill(rd, seq, qual, offsets, cap_bytes, cap_reads, &total, &uniform);
     if (n < 0) {
       host_fail(n == -4 ? "%s: a read exceeds the batch size (raise QUACK_HIP_BATCH_MB)"
@@ -70,6 +83,7 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
     }
     turn = (turn + 1) % n_devices;
   }
+  t_parsed = now_s();
   if (n_devices > 1 && qk_accum_allreduce(accs, n_devices)) {
     host_fail("%s", qk_last_error());
     goto out;
@@ -91,6 +105,9 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       goto out;
     }
   }
+  if (verbose)
+    fprintf(stderr, "[quack] %s: accumulators %.3f s, first slot %.3f s, parse+submit %.3f s, drain+finish %.3f s\n",
+            path, t_created - t0, t_first - t_created, t_parsed - t_first, now_s() - t_parsed);
   rc = 0;
 out:
   if (rd) qkh_reader_close(rd);

@@ -178,6 +178,48 @@ def test_many_submits_and_table_growth():
     assert_same((sd.bases, sd.number_of_sequences), ob.accumulate_batch(seq, qual, off))
 
 
+def test_submits_from_several_streams_into_one_accumulator():
+    """device-resident batches enqueued from three streams, un-synchronised, with
+    pinned-slot batches in between: launches of one accumulator share its work
+    queues and first-hit scratch, so the shim orders them itself"""
+    import torch
+    adapters = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(adapters)
+    parts = []
+    for i in range(24):
+        lo, hi = [(1, 150), (1000, 9000), (100, 700)][i % 3]
+        seq, qual, off = synth.ragged([4000, 300, 1500][i % 3], lo, hi, seed=100 + i)
+        rng = np.random.default_rng(i)
+        for r in rng.integers(0, len(off) - 1, (len(off) - 1) // 3):     # adapters anywhere in a third of the reads
+            a, b = int(off[r]), int(off[r + 1])
+            ad = np.frombuffer(adapters[int(rng.integers(0, len(adapters)))], np.uint8)
+            at = a + int(rng.integers(0, max(1, b - a)))
+            m = min(len(ad), b - at)
+            seq[at:at + m] = ad[:m]
+        parts.append((seq, qual, off))
+    streams = [torch.cuda.Stream(device=0) for _ in range(3)]
+    keep = []
+    with quack_amd.Accumulator(0, ob.kmers_to_bitset(k)) as acc:
+        for i, (seq, qual, off) in enumerate(parts):
+            if i % 4 == 3:
+                acc.submit(seq, qual, off)          # through the pinned slots and their streams
+                continue
+            st = streams[i % 3]
+            with torch.cuda.stream(st):
+                d = [torch.from_numpy(pad_for_device(seq)).to("cuda:0", non_blocking=True),
+                     torch.from_numpy(pad_for_device(qual)).to("cuda:0", non_blocking=True),
+                     torch.from_numpy(off.astype(np.int64)).to("cuda:0", non_blocking=True)]
+            keep.append(d)
+            max_len = int(np.diff(off.astype(np.int64)).max())
+            acc.submit_device(d[0], d[1], d[2], len(off) - 1, len(seq), max_len, stream=st.cuda_stream)
+        sd = acc.finish()
+    seq = np.concatenate([p[0] for p in parts])
+    qual = np.concatenate([p[1] for p in parts])
+    lens = np.concatenate([np.diff(p[2].astype(np.int64)) for p in parts])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    assert_same((sd.bases, sd.number_of_sequences), ob.accumulate_batch(seq, qual, off, kmers=k))
+
+
 def test_pinned_pipeline_many_small_batches(monkeypatch):
     monkeypatch.setenv("QUACK_HIP_BATCH_MB", "1")
     seq, qual, off = synth.ragged(60000, 50, 150, seed=21)       # ~6 MB -> >= 6 slot turnovers
