@@ -160,7 +160,7 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 #ifndef QK_MIN_WAVES_PER_SIMD
 #define QK_MIN_WAVES_PER_SIMD 1   // experiments: (T/256)*k asks for k workgroups per CU
 #endif
-template <int T, int U, bool FIXED, int MODE, bool ADAPT = false>
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1>
 __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
   extern __shared__ uint32_t lds[];
   const uint32_t tid = threadIdx.x;
@@ -391,9 +391,11 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         }
       }
 
-      for (uint32_t it = 0; it < n_list; it += RW * U) {
-        u32x3 q[U], s[U];
-        uint32_t nv[U], sk[U], ridx[U];
+      // One step = RW*U reads: `issue` computes the addresses and starts the
+      // loads, `consume` histograms them.  With PD > 1 the loads of step k+1
+      // are in flight while step k is consumed (PD register sets).
+      auto issue = [&](uint32_t it, u32x3 (&q)[U], u32x3 (&s)[U], uint32_t (&nv)[U], uint32_t (&sk)[U],
+                       uint32_t (&ridx)[U]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t rel = it + (uint32_t)u * RW + ri;   // index into the slice (FIXED) / the staged list
@@ -430,6 +432,9 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
             }
           }
         }
+      };
+      auto consume = [&](const u32x3 (&q)[U], const u32x3 (&s)[U], const uint32_t (&nv)[U], const uint32_t (&sk)[U],
+                         const uint32_t (&ridx)[U]) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // bytes past the end of the read -> 0xFF: quality row 127 is discarded
@@ -543,6 +548,29 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         if (MODE == 0 || MODE == 3) {
           since_spill += U;
           if (since_spill + U > 255u) spill();   // byte counters hold <= 255
+        }
+      };
+      if constexpr (PD > 1) {
+        // PD register sets: the loads of the next PD-1 steps are in flight
+        // while one step is consumed
+        u32x3 q[PD][U], s[PD][U];
+        uint32_t nv[PD][U], sk[PD][U], ridx[PD][U];
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d) issue((uint32_t)d * RW * U, q[d], s[d], nv[d], sk[d], ridx[d]);
+        for (uint32_t it = 0; it < n_list; it += (uint32_t)PD * RW * U) {
+#pragma unroll
+          for (int d = 0; d < PD; ++d) {
+            const int nx = (d + PD - 1) % PD;
+            issue(it + (uint32_t)(d + PD - 1) * RW * U, q[nx], s[nx], nv[nx], sk[nx], ridx[nx]);
+            if (d == 0 || it + (uint32_t)d * RW * U < n_list) consume(q[d], s[d], nv[d], sk[d], ridx[d]);
+          }
+        }
+      } else {
+        for (uint32_t it = 0; it < n_list; it += RW * U) {
+          u32x3 q[U], s[U];
+          uint32_t nv[U], sk[U], ridx[U];
+          issue(it, q, s, nv, sk, ridx);
+          consume(q, s, nv, sk, ridx);
         }
       }
     }

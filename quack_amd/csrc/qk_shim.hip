@@ -99,7 +99,7 @@ struct qk_accum {
   hipStream_t order_stream = nullptr;
   bool order_valid = false;
   // tuning
-  int threads = 1024, unroll = 4, tile = 0, wgs_per_cu = 0;   // 0 = automatic
+  int threads = 1024, unroll = 0, pipe = 0, tile = 0, wgs_per_cu = 0;   // 0 = automatic
   // timing
   bool timing = false;
   std::vector<TimedLaunch> timed;
@@ -157,6 +157,7 @@ int grow_table(qk_accum *a, uint64_t need, bool exact = false) {
 
 struct Plan {
   uint32_t n_tiles, tile_pos, ch, rw;
+  int unroll, pipe;
   uint64_t reads_per_slice, n_slices, n_blocks;
   uint32_t bucket_log2, halo;
   bool fused_adapters, dynamic;
@@ -171,7 +172,18 @@ constexpr unsigned kQueueTiles = 8192;  // counters per launch
 // Longer reads get tiles of <= 512 positions.  The grid is sized to residency:
 // workgroups per CU = what the LDS admits (at most 2 of 1024 threads).
 int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, Plan *pl) {
-  const uint32_t T = (uint32_t)a->threads, U = (uint32_t)a->unroll;
+  const uint32_t T = (uint32_t)a->threads;
+  pl->fused_adapters = a->adapters && !getenv("QUACK_HIP_UNFUSED_ADAPTERS");
+  // reads per lane and step / software pipeline depth.  Measured (10M x 150,
+  // 5M x 300 + adapters, 1-20 kb ragged; kbench): fixed-length batches like
+  // the next step's loads in flight while one is consumed — with one read per
+  // step when there is no adapter scan (70 VGPRs, 0.546 -> 0.527 ms), four
+  // with it (0.915 -> 0.878 ms); the ragged path (LDS-staged descriptors) is
+  // best unpipelined.
+  const bool want_pipe = a->pipe > 0 ? a->pipe > 1 : (a->unroll <= 0 && !ragged && T == 1024);
+  pl->pipe = a->pipe > 0 ? a->pipe : (want_pipe ? 2 : 1);
+  pl->unroll = a->unroll > 0 ? a->unroll : ((want_pipe && !ragged && !pl->fused_adapters) ? 1 : 4);
+  const uint32_t U = (uint32_t)pl->unroll;
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
   uint32_t single_cap = 576u;
   while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, a->adapters, a->adapters ? a->bucket_log2 : 0, ragged) > 160 * 1024)
@@ -183,7 +195,6 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
     cap = 512;
     n_tiles = (max_len + cap - 1) / cap;
   }
-  pl->fused_adapters = a->adapters && !getenv("QUACK_HIP_UNFUSED_ADAPTERS");
   const uint32_t lanes = pl->fused_adapters ? T / 64 * 62 : T;   // two feeder lanes per wave when fused
   if (cap / 8 + 2 > lanes) {
     cap = (lanes - 2) * 8;
@@ -239,23 +250,23 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   return QK_OK;
 }
 
-template <int T, int U>
+template <int T, int U, int PD>
 int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, dim3 grid,
                    size_t lds, hipStream_t st) {
   void (*k)(const qk::HistParams) = nullptr;
   if (adapt) {
-    if (mode == 0) k = fixed ? qk::hist_kernel<T, U, true, 0, true> : qk::hist_kernel<T, U, false, 0, true>;
+    if (mode == 0) k = fixed ? qk::hist_kernel<T, U, true, 0, true, PD> : qk::hist_kernel<T, U, false, 0, true, PD>;
   } else if (fixed) {
     switch (mode) {
-      case 0: k = qk::hist_kernel<T, U, true, 0>; break;
+      case 0: k = qk::hist_kernel<T, U, true, 0, false, PD>; break;
 #ifdef QK_ABLATION
-      case 1: k = qk::hist_kernel<T, U, true, 1>; break;
-      case 2: k = qk::hist_kernel<T, U, true, 2>; break;
-      case 3: k = qk::hist_kernel<T, U, true, 3>; break;
+      case 1: k = qk::hist_kernel<T, U, true, 1, false, PD>; break;
+      case 2: k = qk::hist_kernel<T, U, true, 2, false, PD>; break;
+      case 3: k = qk::hist_kernel<T, U, true, 3, false, PD>; break;
 #endif
     }
   } else {
-    if (mode == 0) k = qk::hist_kernel<T, U, false, 0>;
+    if (mode == 0) k = qk::hist_kernel<T, U, false, 0, false, PD>;
   }
   if (!k) return fail(QK_EINVAL, "kernel variant not built (mode %d)", mode);
   QK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -264,17 +275,18 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, d
   return QK_OK;
 }
 
-int launch_hist(qk_accum *a, const qk::HistParams &hp, bool fixed, int mode, bool adapt,
-                uint64_t n_blocks, hipStream_t st) {
+int launch_hist(qk_accum *a, const qk::HistParams &hp, const Plan &pl, bool fixed, int mode, bool adapt,
+                hipStream_t st) {
   const size_t lds = qk::hist_lds_bytes(hp.ch, adapt, hp.bucket_log2, !fixed);
-  dim3 grid((unsigned)n_blocks);
-#define QK_TU(TT, UU) \
-  if (a->threads == TT && a->unroll == UU) return launch_hist_tu<TT, UU>(hp, fixed, mode, adapt, grid, lds, st);
-  QK_TU(1024, 4) QK_TU(1024, 2) QK_TU(1024, 1)
-  QK_TU(512, 4) QK_TU(512, 2) QK_TU(512, 1)
-  QK_TU(256, 4) QK_TU(256, 2)
+  dim3 grid((unsigned)pl.n_blocks);
+#define QK_TU(TT, UU, PP) \
+  if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, grid, lds, st);
+  QK_TU(1024, 4, 1) QK_TU(1024, 2, 1) QK_TU(1024, 1, 1)
+  QK_TU(1024, 4, 2) QK_TU(1024, 2, 2) QK_TU(1024, 1, 2)
+  QK_TU(512, 4, 1) QK_TU(512, 2, 1) QK_TU(512, 1, 1)
+  QK_TU(256, 4, 1) QK_TU(256, 2, 1)
 #undef QK_TU
-  return fail(QK_EINVAL, "unsupported threads/unroll %d/%d", a->threads, a->unroll);
+  return fail(QK_EINVAL, "unsupported threads/unroll/pipe %d/%d/%d", a->threads, pl.unroll, pl.pipe);
 }
 
 hipEvent_t get_event(qk_accum *a) {
@@ -346,7 +358,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     QK_HIP(hipEventRecord(tl.t0, st));
   }
   if (pl.fused_adapters) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
-  rc = launch_hist(a, hp, d_off == nullptr, g_ablation_mode, pl.fused_adapters, pl.n_blocks, st);
+  rc = launch_hist(a, hp, pl, d_off == nullptr, g_ablation_mode, pl.fused_adapters, st);
   if (rc) return rc;
   if (a->timing) {
     QK_HIP(hipEventRecord(tl.t1, st));
@@ -430,6 +442,7 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
     a->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     a->threads = env_int("QUACK_HIP_THREADS", a->threads);
     a->unroll = env_int("QUACK_HIP_UNROLL", a->unroll);
+    a->pipe = env_int("QUACK_HIP_PIPE", a->pipe);
     a->tile = env_int("QUACK_HIP_TILE", a->tile);
     a->wgs_per_cu = env_int("QUACK_HIP_WGS_PER_CU", a->wgs_per_cu);
     if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess ||

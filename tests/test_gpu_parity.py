@@ -239,6 +239,27 @@ def test_launch_configurations_are_equivalent(cfg):
     assert_same(hip_table(seq, qual, read_len=150, **cfg), ob.accumulate_batch(seq, qual, read_len=150))
 
 
+@pytest.mark.parametrize("unroll,pipe", [("1", "2"), ("2", "2"), ("4", "2"), ("1", "1"), ("4", "1")])
+def test_software_pipelined_variants_are_equivalent(monkeypatch, unroll, pipe):
+    """QUACK_HIP_PIPE=2: the next step's loads are issued before the current
+    step is consumed.  Automatic for fixed-length batches; forced here through
+    every path (ragged staging, several tiles, fused adapters, short reads)"""
+    monkeypatch.setenv("QUACK_HIP_UNROLL", unroll)
+    monkeypatch.setenv("QUACK_HIP_PIPE", pipe)
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    bits = ob.kmers_to_bitset(k)
+    for L, n in ((150, 30011), (36, 50000), (300, 9000), (5, 1000)):
+        seq, qual = synth.fixed(n, L, seed=L)
+        assert_same(hip_table(seq, qual, read_len=L), ob.accumulate_batch(seq, qual, read_len=L))
+        seq = synth.splice_adapters(seq, L, ads, seed=L + 1)
+        assert_same(hip_table(seq, qual, read_len=L, kmers_bits=bits), ob.accumulate_batch(seq, qual, read_len=L, kmers=k))
+    for n, lo, hi in ((30000, 1, 150), (300, 1000, 9000), (2500, 1, 40)):
+        seq, qual, off = synth.ragged(n, lo, hi, seed=hi)
+        assert_same(hip_table(seq, qual, off), ob.accumulate_batch(seq, qual, off))
+        assert_same(hip_table(seq, qual, off, kmers_bits=bits), ob.accumulate_batch(seq, qual, off, kmers=k))
+
+
 def test_empty_inputs():
     with quack_amd.Accumulator(0) as acc:
         acc.submit(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))

@@ -309,7 +309,10 @@ int main(int argc, char **argv) {
   std::vector<Cfg> cfgs = {
       {1024, 4, 192, 2}, {1024, 2, 192, 2}, {1024, 1, 192, 2}, {512, 4, 192, 4}, {512, 2, 192, 4},
       {256, 4, 192, 8},  {1024, 4, 192, 1}, {1024, 4, 192, 4}, {512, 4, 192, 8}, {1024, 4, 304, 1},
-      {512, 4, 304, 2},  {1024, 4, 96, 2},  {1024, 4, 0, 0} /* 12: planner defaults */,
+      {512, 4, 304, 2},  {1024, 4, 96, 2},  {1024, 0, 0, 0} /* 12: planner defaults */,
+      {1024, 2, 0, 0}, {1024, 1, 0, 0}, {512, 4, 0, 0}, {512, 2, 0, 0} /* 13-16: planner tiles, other T/U */,
+      {512, 1, 0, 0}, {512, 1, 0, 3}, {512, 2, 0, 3}, {256, 1, 0, 6}, {256, 2, 0, 5} /* 17-21 */,
+      {1024, 1, 0, 2}, {512, 1, 0, 4}, {512, 1, 0, 2} /* 22-24 */,
   };
   const int modes_fixed[] = {0, 1, 2, 3};
   const double alg_bytes = 2.0 * total + (ragged ? 8.0 * n_reads : 0.0);
