@@ -11,7 +11,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline $*"
 echo "== kernel trace"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+# same step counts as the default bench line, so that the two averages are comparable
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline $* > $OUT/trace.log 2>&1
 echo "== pmc FETCH_SIZE"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 echo "== pmc WRITE_SIZE"

@@ -73,7 +73,7 @@ def main():
     json.dump(t, open(tf, "w"), indent=1)
     with open(os.path.join(dst, tag + "_summary.md"), "w") as f:
         f.write("# rocprofv3 summary %s (%s)\n\n" % (tag, workload))
-        f.write("Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline%s`\n\n"
+        f.write("Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline%s` (200 steps + 50 warm-up; PMC passes: `--steps 20 --warmup 3`)\n\n"
                 % ("" if workload == "cfg2" else " --workload " + workload))
         f.write("| kernel | calls | avg µs | min µs | max µs | algorithmic GB/s |\n|---|---|---|---|---|---|\n")
         f.write("| `%s` | %d | %.1f | %.1f | %.1f | %.0f |\n\n" % (k["Name"], info["calls"], info["avg_ns"] / 1e3,
