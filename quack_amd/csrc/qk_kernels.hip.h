@@ -98,16 +98,17 @@ __device__ __forceinline__ void lds_add(uint32_t *lds, uint32_t byte_off,
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Per-byte "== K" indicator (0/1 in each byte) on the 5-bit letter key.
+// Per-byte "!= K" indicator (0/1 in each byte) on the 5-bit letter key.
 // quack.c:148-150,201 maps letters by (c-65)&~32: T->1, C->2, G->3, every
 // other letter of its defined domain (A..T, a..t) -> 0.  (c & 31) is injective
 // on that domain: T=20, C=3, G=7.  Bytes outside it index lookup[] out of
 // bounds in the reference (undefined); here they alias the letter with the
-// same low five bits.
-__device__ __forceinline__ uint32_t swar_eq(uint32_t w, uint32_t k4) {
-  const uint32_t y = (w & 0x1F1F1F1Fu) ^ k4;   // 0 in matching bytes, <= 0x1F
-  const uint32_t z = y + 0x7F7F7F7Fu;          // bit 7 of a byte <=> byte != 0
-  return ~(z >> 7) & 0x01010101u;
+// same low five bits.  The kernels count "not the letter" (one instruction
+// shorter than the equality) and take events - count when they spill.
+__device__ __forceinline__ uint32_t swar_ne(uint32_t w, uint32_t k4) {
+  const uint32_t y = (w & 0x1F1F1F1Fu) ^ k4;
+  const uint32_t z = y + 0x7F7F7F7Fu;
+  return (z >> 7) & 0x01010101u;
 }
 
 constexpr uint32_t kKeyT = 0x14141414u, kKeyC = 0x03030303u, kKeyG = 0x07070707u;
@@ -221,6 +222,16 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   // SWAR byte counters for the 8 owned positions: [0] positions 0-3, [1] 4-7
   uint32_t acc_v[2] = {0, 0}, acc_t[2] = {0, 0}, acc_c[2] = {0, 0}, acc_g[2] = {0, 0};
   uint32_t since_spill = 0;
+  // acc_t/c/g count the bytes that are NOT T/C/G (swar_ne, one instruction
+  // shorter than the equality) and acc_v the events in which a byte was masked;
+  // the spill takes events - count.  Masked bytes are "not equal" in every
+  // event, so they come out as zero.  `events` = accumulated steps since the
+  // last spill (wave-uniform).  Fixed-length batches without the adapter scan
+  // go one step further: the tail masks are per-lane constants (fm0/fm1), lanes past
+  // the end of the slice sit out under the exec mask and count their own
+  // events (steps_v), and no per-event valid counter is needed at all.
+  constexpr bool FAST_FIXED = FIXED && !ADAPT;
+  uint32_t events = 0, steps_v = 0, fm0 = 0xFFFFFFFFu, fm1 = 0xFFFFFFFFu;
 
   auto spill = [&]() {
 #pragma unroll
@@ -228,12 +239,19 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const uint32_t off = (8u * ch + 4u * d + b) * 4u;
-        const uint32_t v = (acc_v[d] >> (8 * b)) & 0xFFu;
+        uint32_t v = events - ((acc_v[d] >> (8 * b)) & 0xFFu);   // acc_v counts the events in which the byte was masked
+        if (FAST_FIXED) v = (((d ? fm1 : fm0) >> (8 * b)) & 0xFFu) ? 0u : steps_v;
         if (v == 0) continue;  // nothing valid => no T/C/G either
         lds_add(lds_base, off, v);
-        const uint32_t t = (acc_t[d] >> (8 * b)) & 0xFFu;
-        const uint32_t c = (acc_c[d] >> (8 * b)) & 0xFFu;
-        const uint32_t g = (acc_g[d] >> (8 * b)) & 0xFFu;
+        uint32_t t = (acc_t[d] >> (8 * b)) & 0xFFu;
+        uint32_t c = (acc_c[d] >> (8 * b)) & 0xFFu;
+        uint32_t g = (acc_g[d] >> (8 * b)) & 0xFFu;
+        {
+          const uint32_t ev = FAST_FIXED ? steps_v : events;
+          t = ev - t;
+          c = ev - c;
+          g = ev - g;
+        }
         if (t) lds_add(lds_base, off + 4u * TP, t);
         if (c) lds_add(lds_base, off + 8u * TP, c);
         if (g) lds_add(lds_base, off + 12u * TP, g);
@@ -241,6 +259,8 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
       acc_v[d] = acc_t[d] = acc_c[d] = acc_g[d] = 0;
     }
     since_spill = 0;
+    events = 0;
+    steps_v = 0;
   };
 
   auto zero_lds = [&]() {
@@ -326,6 +346,12 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     const uint64_t room = p.total_bytes - base_al;   // total_bytes >= base_al when slice_reads > 0
     const uint32_t off_limit = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
     const uint32_t cposp = cpos + (uint32_t)(slice_base & 3ull);
+    if (FIXED) {
+      // the lane's chunk covers the same bytes of every read of the batch
+      const uint32_t nc = (lane_on && p.read_len > cpos) ? (p.read_len - cpos > 8u ? 8u : p.read_len - cpos) : 0u;
+      fm0 = nc >= 4u ? 0u : (0xFFFFFFFFu << (8u * nc));
+      fm1 = nc >= 8u ? 0u : (nc <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (nc - 4u))));
+    }
     // windows ending before position 9 do not exist
     const uint32_t win_mask = cpos >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cpos)) - 1u));
 
@@ -444,11 +470,15 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         // reads): the whole wave moves on.  ADAPT needs every lane's codes, but
         // then no lane has a valid window either.
         if (!FIXED && __builtin_amdgcn_ballot_w64(n != 0) == 0) continue;
+        if (FAST_FIXED && n == 0) continue;   // per lane: past the end of the slice (its last step only)
         const uint2 qa = window8(q[u], sk[u]);
         const uint2 sa = window8(s[u], sk[u]);
-        const uint32_t m0 = n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n));
-        const uint32_t m1 = n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu
-                                                     : (0xFFFFFFFFu << (8u * (n - 4u))));
+        // tail masks: per-lane constants in a fixed-length batch (n is then
+        // the lane's constant or, past the end of the slice, zero)
+        const uint32_t m0 = FAST_FIXED ? fm0 : FIXED ? (n ? fm0 : 0xFFFFFFFFu)
+                                             : (n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n)));
+        const uint32_t m1 = FAST_FIXED ? fm1 : FIXED ? (n ? fm1 : 0xFFFFFFFFu)
+                                             : (n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (n - 4u)))));
         const uint32_t mk[2] = {m0, m1};
         const uint32_t qw[2] = {qa.x | m0, qa.y | m1};
         const uint32_t sw[2] = {sa.x | m0, sa.y | m1};
@@ -468,27 +498,39 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           // needs them (feeder lanes and chunk tails must still yield the real
           // codes; window validity is enforced by `hits` masks below) and are
           // masked per byte for the content counters
-          uint32_t et[2], ec[2], eg[2];
+          uint32_t b0[2], b1[2];
           const uint32_t raw[2] = {sa.x, sa.y};
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
-            const uint32_t valid01 = ~mk[d] & 0x01010101u;
-            const uint32_t src = ADAPT ? raw[d] : sw[d];
-            et[d] = swar_eq(src, kKeyT);
-            ec[d] = swar_eq(src, kKeyC);
-            eg[d] = swar_eq(src, kKeyG);
-            acc_v[d] += valid01;
-            acc_t[d] += ADAPT ? (et[d] & valid01) : et[d];
-            acc_c[d] += ADAPT ? (ec[d] & valid01) : ec[d];
-            acc_g[d] += ADAPT ? (eg[d] & valid01) : eg[d];
+            if (!ADAPT) {
+              acc_t[d] += swar_ne(sw[d], kKeyT);
+              acc_c[d] += swar_ne(sw[d], kKeyC);
+              acc_g[d] += swar_ne(sw[d], kKeyG);
+              if (!FAST_FIXED) acc_v[d] += mk[d] & 0x01010101u;   // invalid events
+              b0[d] = b1[d] = 0;
+            } else {
+              // the scan needs the indicators of the real bytes; the counters
+              // need every masked byte to read "not equal"
+              const uint32_t inv01 = mk[d] & 0x01010101u;
+              const uint32_t nt = swar_ne(raw[d], kKeyT), nc = swar_ne(raw[d], kKeyC), ng = swar_ne(raw[d], kKeyG);
+              acc_t[d] += nt | inv01;
+              acc_c[d] += nc | inv01;
+              acc_g[d] += ng | inv01;
+              acc_v[d] += inv01;
+              // code bits: low = T or G, high = C or G (at most one letter matches)
+              b0[d] = (nt & ng) ^ 0x01010101u;
+              b1[d] = (nc & ng) ^ 0x01010101u;
+            }
           }
+          if (FAST_FIXED) steps_v += 1u;
+          else events += 1u;
           if (ADAPT) {
             // 2-bit codes A0 T1 C2 G3 (quack.c:150) of the 8 owned bases, first
             // base most significant: byte codes -> 8 bits per dword by multiply
             uint32_t c8[2];
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
-              const uint32_t cb = ((ec[d] + eg[d]) << 1) + (et[d] + eg[d]);
+              const uint32_t cb = (b1[d] << 1) + b0[d];
               c8[d] = (cb * 0x40100401u) >> 24;
             }
             const uint32_t own16 = (c8[0] << 8) | c8[1];
