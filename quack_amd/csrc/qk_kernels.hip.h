@@ -145,6 +145,20 @@ __device__ __forceinline__ bool bucket_has(const uint4 *buckets, uint32_t km, ui
   return zero_half(x0) | zero_half(x1) | zero_half(x2) | zero_half(x3);
 }
 
+// Byte at an absolute LDS address.  The adapter kernels keep their window
+// filter at LDS byte 0 (first thing in the dynamic segment; they have no static
+// LDS, which launch_hist checks), so a probe's address is the key field itself
+// — the address of an `extern __shared__` array is a link-time constant the
+// compiler would otherwise add per probe.
+typedef const __attribute__((address_space(3))) uint8_t lds_const_u8;
+__device__ __forceinline__ uint32_t lds_abs_u8(uint32_t byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(lds_const_u8 *)byte_addr;
+#else
+  return byte_addr & 0u;   // host pass of the single-source compile: never called
+#endif
+}
+
 // value of the same register in lane-1 (v_mov_b32_dpp wave_shr:1); lane 0 gets 0
 __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
@@ -163,7 +177,10 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 #endif
 template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1>
 __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
-  extern __shared__ uint32_t lds[];
+  extern __shared__ uint32_t lds_raw[];
+  // ADAPT: the window filter sits first, so that the probes' LDS addresses are
+  // "field + constant" (no per-probe add of a layout-dependent base)
+  uint32_t *lds = lds_raw + (ADAPT ? kFusedFilterWords : 0u);
   const uint32_t tid = threadIdx.x;
   const uint32_t CH = p.ch;
   const uint32_t RD = p.row_dwords;
@@ -172,14 +189,15 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   uint32_t *lds_base = lds + hist_words;  // [4][TP]
   uint32_t *lds_len = lds_base + 4u * TP;
   uint32_t *lds_misc = lds_len + TP;      // [0] reads longer than 10, [1] next item
-  uint32_t *lds_filter = lds_misc + 4u;   // ADAPT only
-  const uint8_t *filt8 = reinterpret_cast<const uint8_t *>(lds_filter);
-  // (hist words, 5*TP, 4 and the filter are all multiples of 4 dwords: 16-byte aligned)
-  uint4 *lds_buckets = reinterpret_cast<uint4 *>(lds_filter + kFusedFilterWords);
+  uint32_t *lds_filter = lds_raw;         // ADAPT only
+  const uint8_t *filt8 = reinterpret_cast<const uint8_t *>(lds_raw);   // == LDS byte 0, see lds_abs_u8
+  (void)filt8;
+  // (the filter, hist words, 5*TP and 4 are all multiples of 4 dwords: 16-byte aligned)
+  uint4 *lds_buckets = reinterpret_cast<uint4 *>(lds_misc + 4u);
   // ragged batches: descriptors {start - slice base, length [| index << 16]} of
   // the reads of the current pass that reach this tile, compacted
   uint2 *lds_list = reinterpret_cast<uint2 *>(
-      reinterpret_cast<char *>(lds_misc + 4u) + (ADAPT ? kFusedFilterWords * 4u + (p.bucket_log2 ? (16u << p.bucket_log2) : 0u) : 0u));
+      reinterpret_cast<char *>(lds_misc + 4u) + ((ADAPT && p.bucket_log2) ? (16u << p.bucket_log2) : 0u));
   uint32_t *lds_ridx = reinterpret_cast<uint32_t *>(lds_list + kStageReads);   // ADAPT: index of a staged read within its pass
   const uint64_t TL = p.table_len;
 
@@ -556,11 +574,17 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
               hits = x == 0x7F7u ? 1u : 0u;
             }
 #elif !defined(QK_ABLATE_NO_FILTER)
+            {
+              // all eight reads first (one wait), then the bit tests; the
+              // answers are shifted in from the top (v_alignbit), window 0 first
+              uint32_t byt[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const int sh = 2 * (7 - j);
-              const uint32_t byte = filt8[__builtin_amdgcn_ubfe(plo, sh + 3, kFusedFilterLog2 - 3)];
-              hits |= __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(plo, sh, 3), 1) << j;
+              for (int j = 0; j < 8; ++j) byt[j] = lds_abs_u8(__builtin_amdgcn_ubfe(plo, 2 * (7 - j) + 3, kFusedFilterLog2 - 3));
+              uint32_t acc = 0;
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                acc = __builtin_amdgcn_alignbit(byt[j] >> __builtin_amdgcn_ubfe(plo, 2 * (7 - j), 3), acc, 1);
+              hits = acc >> 24;
             }
 #else
             hits = (plo == 0x12345u) ? 1u : 0u;   // ablation: keep the codes alive, no LDS probes

@@ -269,6 +269,16 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, d
     if (mode == 0) k = qk::hist_kernel<T, U, false, 0, false, PD>;
   }
   if (!k) return fail(QK_EINVAL, "kernel variant not built (mode %d)", mode);
+  if (adapt) {
+    // the fused scan addresses its filter at LDS byte 0 (qk::lds_abs_u8)
+    static bool checked = false;   // per instantiation
+    if (!checked) {
+      hipFuncAttributes fa;
+      QK_HIP(hipFuncGetAttributes(&fa, (const void *)k));
+      if (fa.sharedSizeBytes != 0) return fail(QK_ESTATE, "adapter kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
+      checked = true;
+    }
+  }
   QK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(T), lds, st, hp);
   QK_HIP(hipGetLastError());
