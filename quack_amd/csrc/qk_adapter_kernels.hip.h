@@ -208,7 +208,9 @@ inline bool build_kmer_buckets(const uint32_t *host_bits, uint32_t max_log2, std
 inline int upload_kmer_tables(const uint32_t *host_bits, uint32_t **d_bits, uint32_t **d_filter,
                               uint32_t *filter_bits) {
   const uint32_t words = 1u << 15;  // 2^20 bits
-  uint32_t *filt = (uint32_t *)calloc(kFilterBits / 32, sizeof(uint32_t));
+  // [first level: 2^18 bits by the window's low 18 bits | second level (fused
+  // path only): 2^17 bits by its top 17 bits]
+  uint32_t *filt = (uint32_t *)calloc(kFusedFilterWords, sizeof(uint32_t));
   if (!filt) return (int)hipErrorOutOfMemory;
   for (uint32_t w = 0; w < words; ++w) {
     uint32_t v = host_bits[w];
@@ -218,12 +220,14 @@ inline int upload_kmer_tables(const uint32_t *host_bits, uint32_t **d_bits, uint
       const uint32_t km = w * 32u + b;
       const uint32_t h = km & (kFilterBits - 1u);
       filt[h >> 5] |= 1u << (h & 31u);
+      const uint32_t h2 = km >> 3;   // 17 bits; byte h2 >> 3, bit h2 & 7 — as the kernel reads it
+      filt[kFilterBits / 32 + (h2 >> 5)] |= 1u << (h2 & 31u);
     }
   }
   hipError_t e = hipMalloc((void **)d_bits, words * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemcpy(*d_bits, host_bits, words * sizeof(uint32_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc((void **)d_filter, kFilterBits / 8);
-  if (e == hipSuccess) e = hipMemcpy(*d_filter, filt, kFilterBits / 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void **)d_filter, kFusedFilterWords * 4);
+  if (e == hipSuccess) e = hipMemcpy(*d_filter, filt, kFusedFilterWords * 4, hipMemcpyHostToDevice);
   free(filt);
   *filter_bits = kFilterBits;
   return (int)e;

@@ -120,14 +120,23 @@ constexpr uint32_t kKeyT = 0x14141414u, kKeyC = 0x03030303u, kKeyG = 0x07070707u
 // columns, picked by (read index in the iteration) % R, spread them over the
 // banks; the flush sums the replicas.  R = 1 from 11 chunks per read up (two
 // reads per group collide at most 2-way, which the LDS hides).
-inline __host__ __device__ uint32_t hist_replicas(uint32_t ch) { return ch > 10u ? 1u : (32u + ch - 1u) / ch + 1u; }
-inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch) { return (4u * hist_replicas(ch) * ch + 31u) / 32u * 32u; }
-constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit window filter = 32 KiB of LDS
-constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u;
+// With the adapter tables resident the LDS is tight: the rows then stay within
+// 160 dwords (R <= 40 / CH, one replica fewer for 41-56 and 65-80 bp reads).
+inline __host__ __device__ uint32_t hist_replicas(uint32_t ch, bool adapt = false) {
+  if (ch > 10u) return 1u;
+  const uint32_t r = (32u + ch - 1u) / ch + 1u;
+  return adapt && r > 40u / ch ? 40u / ch : r;
+}
+inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch, bool adapt = false) {
+  return (4u * hist_replicas(ch, adapt) * ch + 31u) / 32u * 32u;
+}
+constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit window filter = 32 KiB of LDS, keyed by the window's low 18 bits
+constexpr uint32_t kFusedFilter2Log2 = 17;  // second level, 16 KiB, keyed by the window's top 17 bits
+constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u + (1u << kFusedFilter2Log2) / 32u;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr uint32_t kStageReads = 1024;      // ragged: read descriptors staged in LDS per pass
 inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false) {
-  return ((size_t)kQRows * hist_row_dwords(ch) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords : 0u)) * sizeof(uint32_t) +
+  return ((size_t)kQRows * hist_row_dwords(ch, adapt) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords : 0u)) * sizeof(uint32_t) +
          (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)kStageReads * (adapt ? 12 : 8) : 0);
 }
 
@@ -592,7 +601,20 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
             // only windows that end inside the read, at e >= 9 (quack.c:206-213)
             hits &= (1u << n) - 1u;
             hits &= win_mask;
-            if (hits) {
+            // Second level, branch-free, for the lane's first candidate: the
+            // first level alone lets ~0.3 % of random windows through (800
+            // adapter 10-mers), i.e. some lane of almost every wave; both
+            // levels together ~2e-5.  Lanes with several candidates go in
+            // regardless (3e-4 of the lanes).
+            bool go;
+            {
+              const uint32_t j1 = (uint32_t)__builtin_ctz(hits | 0x100u) & 7u;
+              const uint32_t w1 = (uint32_t)(((((uint64_t)(prev2 & 3u)) << 32) | plo) >> (2u * (7u - j1))) & 0xFFFFFu;
+              const uint32_t b2 = lds_abs_u8((1u << kFusedFilterLog2) / 8u + (w1 >> 6));
+              const bool pass2 = ((b2 >> ((w1 >> 3) & 7u)) & 1u) != 0;
+              go = hits != 0 && (pass2 || (hits & (hits - 1u)) != 0);
+            }
+            if (go) {
               uint32_t best = kNoHit;
               while (hits) {
                 const int j = __builtin_ctz(hits);

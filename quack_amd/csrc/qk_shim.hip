@@ -355,8 +355,8 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     hp.queue = a->d_queues + (size_t)(a->queue_seq++ % kQueueRing) * kQueueTiles;
     QK_HIP(hipMemsetAsync(hp.queue, 0, pl.n_tiles * sizeof(uint32_t), st));
   }
-  hp.row_dwords = qk::hist_row_dwords(pl.ch);
-  hp.replicas = qk::hist_replicas(pl.ch);
+  hp.row_dwords = qk::hist_row_dwords(pl.ch, pl.fused_adapters);
+  hp.replicas = qk::hist_replicas(pl.ch, pl.fused_adapters);
   hp.halo = pl.halo;
   hp.no_adapters = a->adapters ? 0 : 1;
 

@@ -71,6 +71,22 @@ def test_adapters_fixed(L):
     assert ob.accumulate_batch(seq, qual, read_len=L, kmers=k)[0][:, 96].sum() > 100  # hits happened
 
 
+def test_adapters_every_chunk_count_of_short_reads():
+    """1..14 chunks per read: the replicated-column layouts next to the resident
+    adapter tables (LDS budget), fixed and ragged"""
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    bits = ob.kmers_to_bitset(k)
+    for L in (7, 12, 20, 31, 40, 44, 52, 60, 71, 80, 85, 100, 112):
+        seq, qual = synth.fixed(3000, L, seed=L)
+        seq = synth.splice_adapters(seq, L, ads, seed=L + 1, fraction=0.5)
+        assert_same(hip_table(seq, qual, read_len=L, kmers_bits=bits), ob.accumulate_batch(seq, qual, read_len=L, kmers=k))
+        off = np.arange(0, 3000 * L + 1, L, dtype=np.uint64)
+        off[1:-1] -= np.random.default_rng(L).integers(0, 3, 2999).astype(np.uint64)   # ragged by a base or two
+        off = np.sort(off)
+        assert_same(hip_table(seq, qual, off, kmers_bits=bits), ob.accumulate_batch(seq, qual, off, kmers=k))
+
+
 def test_adapters_ragged_and_long():
     ads = synth.synthetic_adapters()
     k = ob.kmers_from_seqs(ads)
