@@ -20,7 +20,7 @@ hip: $(LIB_HIP)
 $(LIB_HIP): $(CSRC)/qk_shim.hip $(KERNEL_HDRS) include/quack_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/qk_shim.hip -ldl
 
-host:
+host: $(LIB_HIP)
 	$(MAKE) -C $(HOST)
 
 oracle:
