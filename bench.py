@@ -187,6 +187,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        # warm the exchange too (communicator, collective kernels) — on a throwaway
+        # accumulator, so that the measured tables stay the sum of exactly W+K steps
+        with quack_amd.Accumulator(local, None, max_len_hint=max_len) as tmp:
+            qd.allreduce_accumulator(tmp, via_host=args.backend == "gloo")
     fence()
     acc.timing(True)
     if mate is not None:

@@ -2,8 +2,8 @@
 
 The accumulation shards by read batch with no data-path collective (every
 counter update is a commutative integer ++, quack.c:202,204,216,219,220).  At
-the end there is exactly one exchange: all-reduce(MAX) of the table length
-(1 word) and ONE all-reduce(SUM) of the integer tables — `ncclAllReduce` over
+the end there is exactly one exchange: all-reduce(MAX) of the geometry (longest
+read, table length: 2 words) and ONE all-reduce(SUM) of the integer tables — `ncclAllReduce` over
 xGMI when the process group is "nccl" (= RCCL on ROCm), gloo in the CPU tests.
 Integer sums are order-independent, so the result is bit-exact whatever
 algorithm the backend picks.
@@ -39,12 +39,12 @@ def allreduce_accumulator(acc, group=None, via_host=False):
     max_len, _ = acc.stats()
     gpu = torch.device("cuda", acc.device)
     coll = torch.device("cpu") if via_host else gpu
-    ml = torch.tensor([max_len], dtype=torch.int64, device=coll)
-    dist.all_reduce(ml, op=dist.ReduceOp.MAX, group=group)
-    # common geometry first, so that every rank exports the same number of words
-    words = torch.tensor([acc.table_words()], dtype=torch.int64, device=coll)
-    dist.all_reduce(words, op=dist.ReduceOp.MAX, group=group)
-    table_len = (int(words.item()) - 1) // QK_N_ROWS
+    # common geometry first (one MAX over two words), so that every rank exports
+    # the same number of words
+    geo = torch.tensor([max_len, acc.table_words()], dtype=torch.int64, device=coll)
+    dist.all_reduce(geo, op=dist.ReduceOp.MAX, group=group)
+    geo = geo.tolist()
+    table_len = (geo[1] - 1) // QK_N_ROWS
     acc.reserve(table_len)
     assert acc.table_words() == QK_N_ROWS * table_len + 1
     buf = torch.empty(acc.table_words(), dtype=torch.int64, device=gpu)
@@ -58,7 +58,7 @@ def allreduce_accumulator(acc, group=None, via_host=False):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     # a finished NCCL call only orders torch's stream; the shim imports on its own stream
     torch.cuda.current_stream(gpu).synchronize()
-    acc.import_table(buf, int(ml.item()))
+    acc.import_table(buf, geo[0])
     return acc
 
 
