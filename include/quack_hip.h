@@ -111,6 +111,30 @@ int qk_accum_submit_device(qk_accum *acc, const void *d_seq,
                            uint64_t n_reads, uint64_t total_bytes,
                            uint32_t max_len, void *hip_stream);
 
+/* ---- gapped batches: reads need not be adjacent -----------------------------
+ * Read r occupies bytes [starts[r], starts[r] + lengths[r]) of seq / qual;
+ * starts ascend and reads do not overlap; `extent_bytes` is the end of the
+ * last read.  Same counters as the packed form (nothing in the reference
+ * corresponds: it never holds two reads at once, quack.c:193).  What it is for:
+ * with QK_BATCH_ALIGNED128 the producer promises that every read starts on a
+ * 128-byte boundary (one HBM cache line).  Long reads are cut into position
+ * tiles that different workgroups take at different times; with aligned starts
+ * a tile is whole cache lines and every line is fetched once (packed layout:
+ * 5 lines where 4 would do).  The host tokenizer pads long-read batches this
+ * way (quack_amd/host/pipeline.c).  A batch that breaks the promise is
+ * detected: the next qk_accum_sync / finish fails with QK_EINVAL. */
+#define QK_BATCH_ALIGNED128 1u
+
+int qk_accum_submit_device_gapped(qk_accum *acc, const void *d_seq, const void *d_qual,
+                                  const void *d_starts /* u64[n_reads] */,
+                                  const void *d_lengths /* u32[n_reads] */,
+                                  uint64_t n_reads, uint64_t extent_bytes,
+                                  uint32_t max_len, uint32_t flags, void *hip_stream);
+/* Pinned-slot form: between qk_accum_acquire and the commit, `offsets[r]` of
+ * the slot holds starts[r] and the array returned here the lengths. */
+int qk_accum_slot_lengths(qk_accum *acc, uint32_t **lengths);
+int qk_accum_commit_gapped(qk_accum *acc, uint64_t n_reads, uint64_t extent_bytes, uint32_t flags);
+
 /* Wait for everything enqueued so far. */
 int qk_accum_sync(qk_accum *acc);
 

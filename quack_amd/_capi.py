@@ -18,6 +18,7 @@ QK_ROW_LENGTH = 95
 QK_ROW_KMER = 96
 QK_KMER_TABLE_WORDS = (1 << 20) // 32
 QK_TAIL_SLACK = 16
+QK_BATCH_ALIGNED128 = 1
 QK_ENODEV = -2
 
 
@@ -61,6 +62,10 @@ def hip():
     L.qk_accum_submit_fixed.argtypes = [c_vp, c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint64]
     L.qk_accum_submit_device.argtypes = [c_vp, c_vp, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64,
                                          ctypes.c_uint32, c_vp]
+    L.qk_accum_submit_device_gapped.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint64,
+                                                ctypes.c_uint32, ctypes.c_uint32, c_vp]
+    L.qk_accum_slot_lengths.argtypes = [c_vp, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32))]
+    L.qk_accum_commit_gapped.argtypes = [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
     L.qk_accum_sync.argtypes = [c_vp]
     L.qk_accum_stats.argtypes = [c_vp, c_u64p, c_u64p]
     L.qk_accum_table_words.argtypes = [c_vp, c_u64p]

@@ -6,7 +6,7 @@ import tempfile
 import numpy as np
 
 from . import _capi
-from ._capi import QK_KMER_TABLE_WORDS, QK_N_ROWS, QK_TAIL_SLACK
+from ._capi import QK_BATCH_ALIGNED128, QK_KMER_TABLE_WORDS, QK_N_ROWS, QK_TAIL_SLACK
 
 
 class HipUnavailable(RuntimeError):
@@ -158,7 +158,41 @@ class Accumulator:
         _check(self._L.qk_accum_submit_fixed(self._h, seq.ctypes.data, qual.ctypes.data, read_len,
                                              len(seq) // read_len))
 
+    def submit_gapped(self, seq, qual, starts, lengths, aligned=False):
+        """one gapped batch through a pinned slot (qk_accum_acquire / slot_lengths /
+        commit_gapped): read r is seq[starts[r] : starts[r] + lengths[r]]"""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        n, extent = len(starts), len(seq)
+        hs, hq = ctypes.POINTER(ctypes.c_uint8)(), ctypes.POINTER(ctypes.c_uint8)()
+        ho, hl = ctypes.POINTER(ctypes.c_uint64)(), ctypes.POINTER(ctypes.c_uint32)()
+        capb, capr = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(self._L.qk_accum_acquire(self._h, ctypes.byref(hs), ctypes.byref(hq), ctypes.byref(ho),
+                                        ctypes.byref(capb), ctypes.byref(capr)))
+        if extent > capb.value or n > capr.value:
+            self._L.qk_accum_commit(self._h, 0, 0, 0, 0)
+            raise ValueError("batch larger than a pinned slot")
+        _check(self._L.qk_accum_slot_lengths(self._h, ctypes.byref(hl)))
+        ctypes.memmove(hs, seq.ctypes.data, extent)
+        ctypes.memmove(hq, qual.ctypes.data, extent)
+        ctypes.memmove(ho, starts.ctypes.data, 8 * n)
+        ctypes.memmove(hl, lengths.ctypes.data, 4 * n)
+        rc = self._L.qk_accum_commit_gapped(self._h, n, extent, QK_BATCH_ALIGNED128 if aligned else 0)
+        if rc:
+            self._L.qk_accum_commit(self._h, 0, 0, 0, 0)   # give the slot back
+            _check(rc)
+
     # -- device-resident batches (bench / torch plumbing) --------------------
+    def submit_device_gapped(self, d_seq, d_qual, d_starts, d_lengths, n_reads, extent_bytes, max_len,
+                             aligned=False, stream=None):
+        """starts: int64/uint64[n] device tensor, lengths: int32/uint32[n]; see
+        qk_accum_submit_device_gapped"""
+        _check(self._L.qk_accum_submit_device_gapped(
+            self._h, d_seq.data_ptr(), d_qual.data_ptr(), d_starts.data_ptr(), d_lengths.data_ptr(),
+            n_reads, extent_bytes, max_len, QK_BATCH_ALIGNED128 if aligned else 0, stream))
+
     def submit_device(self, d_seq, d_qual, d_offsets, n_reads, total_bytes, max_len, stream=None):
         """d_* expose data_ptr(); buffers need QK_TAIL_SLACK readable bytes
         after total_bytes.  Enqueues only."""

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kScanThreads) void adapter_scan_kernel(const HistPa
       len = p.read_len;
     } else {
       start = p.offsets[r];
-      len = (uint32_t)(p.offsets[r + 1] - start);
+      len = p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - start);
     }
     if (len <= 10u) continue;  // i = 10 >= l: nothing can be counted
     const uint8_t *s = p.seq + start;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kCountThreads) void adapter_count_kernel(const Hist
     if (fh == kNoHit) continue;
     uint32_t len;
     if (FIXED) len = p.read_len;
-    else len = (uint32_t)(p.offsets[r + 1] - p.offsets[r]);
+    else len = p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]);
     const uint32_t i = fh + 1u;      // quack.c:211-213: i ends one past the window
     if (i < len) {                   // quack.c:215
       if (i < kCountLdsPos) atomicAdd(&cnt[i], 1u);

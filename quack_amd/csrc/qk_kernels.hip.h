@@ -52,7 +52,10 @@ constexpr uint32_t kMaxReadsPerSlice = 65535; // u16 counters: <=1 hit/read/pos
 struct HistParams {
   const uint8_t *seq;
   const uint8_t *qual;
-  const uint64_t *offsets;      // NULL => fixed-length batch
+  const uint64_t *offsets;      // NULL => fixed-length batch; else start of every read (+ the end of the last
+                                //   one when `lengths` is NULL: packed batch, read r ends where r+1 starts)
+  const uint32_t *lengths;      // gapped batch: length of every read (NULL: packed)
+  uint32_t *status;             // bit 0 is set when a batch launched as 128-byte aligned is not
   unsigned long long *table;    // planar [kOutRows][table_len]
   uint32_t *first_hit;          // per-read first adapter hit (ADAPT only)
   const uint32_t *kmer_bits;    // 2^20-bit exact table (ADAPT only)
@@ -81,6 +84,12 @@ struct HistParams {
 
 // 12 bytes from a 4-byte-aligned address: one global_load_dwordx3
 struct u32x3 { uint32_t x, y, z; };
+// 8 bytes from an 8-byte-aligned address (batches whose reads start on cache
+// lines: the chunk is aligned as it is)
+__device__ __forceinline__ u32x3 load8_aligned(const uint8_t *p) {
+  const uint2 v = *reinterpret_cast<const uint2 *>(p);
+  return u32x3{v.x, v.y, 0u};
+}
 __device__ __forceinline__ u32x3 load12_aligned(const uint8_t *p) {
   return *reinterpret_cast<const u32x3 *>(__builtin_assume_aligned(p, 4));
 }
@@ -184,7 +193,10 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 #ifndef QK_MIN_WAVES_PER_SIMD
 #define QK_MIN_WAVES_PER_SIMD 1   // experiments: (T/256)*k asks for k workgroups per CU
 #endif
-template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1>
+// AL (ragged only): every read of the batch starts on a 128-byte boundary, so a
+// lane's chunk is 8-byte aligned and a 512-position tile of a read is exactly
+// four cache lines (see QK_BATCH_ALIGNED128 in quack_hip.h).
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false>
 __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
   extern __shared__ uint32_t lds_raw[];
   // ADAPT: the window filter sits first, so that the probes' LDS addresses are
@@ -389,10 +401,11 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     // round trip and never spends a slot on a read that ends before the tile.
     // the offsets of the next pass are requested one pass ahead (each thread
     // stages the read `tid` of a pass), so staging never waits on memory
+    const uint32_t *lbase = (FIXED || !p.lengths) ? nullptr : p.lengths + r_begin;
     uint64_t pf0 = 0, pf1 = 0;
     if (!FIXED && tid < slice_reads) {
       pf0 = obase[tid];
-      pf1 = obase[tid + 1u];
+      pf1 = lbase ? pf0 + lbase[tid] : obase[tid + 1u];
     }
     for (uint32_t pass = 0; pass < slice_reads; pass += FIXED ? slice_reads : kStageReads) {
       uint32_t n_list = slice_reads;   // FIXED: every read of the slice
@@ -411,8 +424,9 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
               len = (uint32_t)(pf1 - pf0);
             } else {
               o0 = obase[pass + i];
-              len = (uint32_t)(obase[pass + i + 1] - o0);
+              len = lbase ? lbase[pass + i] : (uint32_t)(obase[pass + i + 1] - o0);
             }
+            if (AL && (o0 & 127u) != 0) atomicOr(p.status, 1u);   // the producer's promise does not hold
           }
           if (tile == 0 && i < nb) {
             // length_count and the kmers==NULL count (quack.c:215-219), once per read
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         n_list = lds_misc[2];
         if (T == kStageReads && pass + kStageReads + tid < slice_reads) {
           pf0 = obase[pass + kStageReads + tid];
-          pf1 = obase[pass + kStageReads + tid + 1u];
+          pf1 = lbase ? pf0 + lbase[pass + kStageReads + tid] : obase[pass + kStageReads + tid + 1u];
         }
       }
 
@@ -470,9 +484,16 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           n_raw = n_raw > 8u ? 8u : n_raw;
           nv[u] = lane_on ? n_raw : 0u;
           off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
-          sk[u] = off & 3u;
-          off &= ~3u;
-          if (FIXED) {
+          sk[u] = AL ? 0u : (off & 3u);
+          off &= AL ? ~7u : ~3u;
+          if (AL) {
+            q[u] = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            s[u] = q[u];
+            if (n_raw != 0) {
+              q[u] = load8_aligned(qbase + off);
+              s[u] = load8_aligned(sbase + off);
+            }
+          } else if (FIXED) {
             q[u] = load12_aligned(qbase + off);
             s[u] = load12_aligned(sbase + off);
           } else {

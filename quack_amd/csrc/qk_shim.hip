@@ -52,8 +52,10 @@ int env_int(const char *name, int dflt) {
 struct Slot {
   uint8_t *h_seq = nullptr, *h_qual = nullptr;
   uint64_t *h_off = nullptr;
+  uint32_t *h_len = nullptr;          // gapped batches only
   uint8_t *d_seq = nullptr, *d_qual = nullptr;
   uint64_t *d_off = nullptr;
+  uint32_t *d_len = nullptr;
   uint32_t *d_hit = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t done = nullptr;
@@ -95,6 +97,8 @@ struct qk_accum {
   // launches of one accumulator run in submission order even when they come
   // from different streams: they share the queue ring, the first-hit scratch
   // and the table's flush targets
+  uint32_t *d_status = nullptr;       // device word: bit 0 = an "aligned" batch was not aligned
+  bool status_armed = false;
   hipEvent_t order_ev = nullptr;
   hipStream_t order_stream = nullptr;
   bool order_valid = false;
@@ -120,6 +124,8 @@ int ensure_slots(qk_accum *a) {
     QK_HIP(hipHostMalloc((void **)&s.h_seq, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
     QK_HIP(hipHostMalloc((void **)&s.h_qual, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
     QK_HIP(hipHostMalloc((void **)&s.h_off, (a->cap_reads + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    QK_HIP(hipHostMalloc((void **)&s.h_len, a->cap_reads * sizeof(uint32_t), hipHostMallocDefault));
+    QK_HIP(hipMalloc((void **)&s.d_len, a->cap_reads * sizeof(uint32_t)));
     QK_HIP(hipMalloc((void **)&s.d_seq, a->cap_bytes + QK_TAIL_SLACK));
     QK_HIP(hipMalloc((void **)&s.d_qual, a->cap_bytes + QK_TAIL_SLACK));
     QK_HIP(hipMalloc((void **)&s.d_off, (a->cap_reads + 1) * sizeof(uint64_t)));
@@ -160,7 +166,7 @@ struct Plan {
   int unroll, pipe;
   uint64_t reads_per_slice, n_slices, n_blocks;
   uint32_t bucket_log2, halo;
-  bool fused_adapters, dynamic;
+  bool fused_adapters, dynamic, aligned;
 };
 constexpr unsigned kQueueRing = 16;      // launches that may be in flight
 constexpr unsigned kQueueTiles = 8192;  // counters per launch
@@ -171,7 +177,7 @@ constexpr unsigned kQueueTiles = 8192;  // counters per launch
 // (measured on 300 bp: two 152-wide tiles 1.78 ms, one 304-wide tile 1.10 ms).
 // Longer reads get tiles of <= 512 positions.  The grid is sized to residency:
 // workgroups per CU = what the LDS admits (at most 2 of 1024 threads).
-int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, Plan *pl) {
+int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, bool gapped, bool aligned, Plan *pl) {
   const uint32_t T = (uint32_t)a->threads;
   pl->fused_adapters = a->adapters && !getenv("QUACK_HIP_UNFUSED_ADAPTERS");
   // reads per lane and step / software pipeline depth.  Measured (10M x 150,
@@ -202,6 +208,13 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   }
   uint32_t tile_pos = (uint32_t)round_up((max_len + n_tiles - 1) / n_tiles, 8);
   if (tile_pos == 0) tile_pos = 8;
+  // reads that start on cache lines: tiles of whole cache lines (every line is
+  // then fetched by exactly one workgroup); only worth it with several tiles
+  pl->aligned = aligned && ragged && n_tiles > 1 && cap >= 128 && T == 1024 && !a->unroll && !a->pipe;
+  if (pl->aligned) {
+    tile_pos = cap / 128 * 128;
+    n_tiles = (max_len + tile_pos - 1) / tile_pos;
+  }
   pl->n_tiles = n_tiles;
   pl->tile_pos = tile_pos;
   pl->ch = tile_pos / 8;
@@ -231,9 +244,12 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   if (step * 2 > qk::kMaxReadsPerSlice) return fail(QK_EINVAL, "tile too wide for u16 counters");
   uint64_t rcap = (qk::kMaxReadsPerSlice - step) / step * step;
   // the kernel addresses a slice with 32-bit byte offsets
-  const uint64_t by_bytes = (0x7FFFFFFFull / std::max<uint32_t>(max_len, 1)) / step * step;
-  if (by_bytes < step) return fail(QK_EINVAL, "reads of %u bytes are too long for one slice", max_len);
-  rcap = std::min(rcap, by_bytes);
+  // (a gapped batch is < 2 GiB as a whole, checked by the caller: any slice fits)
+  if (!gapped) {
+    const uint64_t by_bytes = (0x7FFFFFFFull / std::max<uint32_t>(max_len, 1)) / step * step;
+    if (by_bytes < step) return fail(QK_EINVAL, "reads of %u bytes are too long for one slice", max_len);
+    rcap = std::min(rcap, by_bytes);
+  }
   if (rps > rcap) {
     // more reads than one residency round may count in u16: whole rounds of
     // equal slices, so that the last round is not a nearly empty one
@@ -251,10 +267,16 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
 }
 
 template <int T, int U, int PD>
-int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, dim3 grid,
+int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, bool aligned, dim3 grid,
                    size_t lds, hipStream_t st) {
   void (*k)(const qk::HistParams) = nullptr;
-  if (adapt) {
+  if (aligned && !fixed && mode == 0) {
+    // only built for the planner's own choice (make_plan sets `aligned` for nothing else)
+    if constexpr (T == 1024 && U == 4 && PD == 1)
+      k = adapt ? qk::hist_kernel<T, U, false, 0, true, PD, true> : qk::hist_kernel<T, U, false, 0, false, PD, true>;
+  }
+  if (k) {
+  } else if (adapt) {
     if (mode == 0) k = fixed ? qk::hist_kernel<T, U, true, 0, true, PD> : qk::hist_kernel<T, U, false, 0, true, PD>;
   } else if (fixed) {
     switch (mode) {
@@ -290,7 +312,7 @@ int launch_hist(qk_accum *a, const qk::HistParams &hp, const Plan &pl, bool fixe
   const size_t lds = qk::hist_lds_bytes(hp.ch, adapt, hp.bucket_log2, !fixed);
   dim3 grid((unsigned)pl.n_blocks);
 #define QK_TU(TT, UU, PP) \
-  if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, grid, lds, st);
+  if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, grid, lds, st);
   QK_TU(1024, 4, 1) QK_TU(1024, 2, 1) QK_TU(1024, 1, 1)
   QK_TU(1024, 4, 2) QK_TU(1024, 2, 2) QK_TU(1024, 1, 2)
   QK_TU(512, 4, 1) QK_TU(512, 2, 1) QK_TU(512, 1, 1)
@@ -315,7 +337,8 @@ int g_ablation_mode = 0;  // set through qk_debug_set_mode (kbench only)
 // Enqueue the kernels of one device-resident batch on `st`.
 int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
                   const uint64_t *d_off, uint32_t *d_hit, uint64_t n_reads,
-                  uint64_t total_bytes, uint32_t max_len, hipStream_t st) {
+                  uint64_t total_bytes, uint32_t max_len, hipStream_t st,
+                  const uint32_t *d_len = nullptr, uint32_t flags = 0) {
   if (n_reads == 0) return QK_OK;
   if (n_reads > 0xFFFFFFF0ull) return fail(QK_EINVAL, "batch too large");
   int rc = grow_table(a, std::max<uint64_t>(max_len, 11));
@@ -325,13 +348,17 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     return QK_OK;
   }
   Plan pl;
-  rc = make_plan(a, n_reads, max_len, d_off != nullptr, &pl);
+  if (d_len && total_bytes > 0x7FFFFFF0ull) return fail(QK_EINVAL, "a gapped batch must stay below 2 GiB");
+  rc = make_plan(a, n_reads, max_len, d_off != nullptr, d_len != nullptr, d_len && (flags & QK_BATCH_ALIGNED128), &pl);
   if (rc) return rc;
   if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));
   qk::HistParams hp{};
   hp.seq = d_seq;
   hp.qual = d_qual;
   hp.offsets = d_off;
+  hp.lengths = d_len;
+  hp.status = a->d_status;
+  if (pl.aligned) a->status_armed = true;
   hp.table = a->d_table;
   hp.first_hit = d_hit;
   hp.kmer_bits = a->d_kmer_bits;
@@ -478,7 +505,9 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
         a->bucket_log2 = 0;   // huge adapter set: filter hits consult the global bitset
       }
     }
-    if (hipMalloc((void **)&a->d_queues, (size_t)kQueueRing * kQueueTiles * sizeof(uint32_t)) != hipSuccess) {
+    if (hipMalloc((void **)&a->d_status, sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(a->d_status, 0, sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&a->d_queues, (size_t)kQueueRing * kQueueTiles * sizeof(uint32_t)) != hipSuccess) {
       rc = fail(QK_EHIP, "hipMalloc failed");
       break;
     }
@@ -501,6 +530,8 @@ void qk_accum_destroy(qk_accum *a) {
     if (s.h_seq) (void)hipHostFree(s.h_seq);
     if (s.h_qual) (void)hipHostFree(s.h_qual);
     if (s.h_off) (void)hipHostFree(s.h_off);
+    if (s.h_len) (void)hipHostFree(s.h_len);
+    if (s.d_len) (void)hipFree(s.d_len);
     if (s.d_seq) (void)hipFree(s.d_seq);
     if (s.d_qual) (void)hipFree(s.d_qual);
     if (s.d_off) (void)hipFree(s.d_off);
@@ -514,6 +545,7 @@ void qk_accum_destroy(qk_accum *a) {
   }
   for (auto e : a->event_pool) (void)hipEventDestroy(e);
   if (a->d_queues) (void)hipFree(a->d_queues);
+  if (a->d_status) (void)hipFree(a->d_status);
   if (a->d_hit_scratch) (void)hipFree(a->d_hit_scratch);
   if (a->d_kmer_bits) (void)hipFree(a->d_kmer_bits);
   if (a->d_kmer_filter) (void)hipFree(a->d_kmer_filter);
@@ -683,6 +715,73 @@ int qk_accum_submit_device(qk_accum *a, const void *d_seq, const void *d_qual,
                        (const uint64_t *)d_offsets, d_hit, n_reads, total_bytes, max_len, st);
 }
 
+int qk_accum_submit_device_gapped(qk_accum *a, const void *d_seq, const void *d_qual,
+                                  const void *d_starts, const void *d_lengths,
+                                  uint64_t n_reads, uint64_t extent_bytes,
+                                  uint32_t max_len, uint32_t flags, void *hip_stream) {
+  if (!a || (n_reads && (!d_starts || !d_lengths || (max_len && (!d_seq || !d_qual))))) return fail(QK_EINVAL, "NULL argument");
+  if (flags & ~QK_BATCH_ALIGNED128) return fail(QK_EINVAL, "unknown flags 0x%x", flags);
+  int rc = set_device(a);
+  if (rc) return rc;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : a->stream;
+  if (hip_stream) a->foreign_stream_used = true;
+  uint32_t *d_hit = nullptr;
+  if (a->adapters) {
+    if (a->hit_scratch_reads < n_reads) {
+      QK_HIP(hipDeviceSynchronize());
+      if (a->d_hit_scratch) QK_HIP(hipFree(a->d_hit_scratch));
+      a->d_hit_scratch = nullptr;
+      a->hit_scratch_reads = 0;
+      QK_HIP(hipMalloc((void **)&a->d_hit_scratch, n_reads * sizeof(uint32_t)));
+      a->hit_scratch_reads = n_reads;
+    }
+    d_hit = a->d_hit_scratch;
+  }
+  return enqueue_batch(a, (const uint8_t *)d_seq, (const uint8_t *)d_qual, (const uint64_t *)d_starts, d_hit,
+                       n_reads, extent_bytes, max_len, st, (const uint32_t *)d_lengths, flags);
+}
+
+int qk_accum_slot_lengths(qk_accum *a, uint32_t **lengths) {
+  if (!a || !lengths) return fail(QK_EINVAL, "NULL argument");
+  if (a->held_slot < 0) return fail(QK_ESTATE, "no batch acquired");
+  *lengths = a->slot[a->held_slot].h_len;
+  return QK_OK;
+}
+
+int qk_accum_commit_gapped(qk_accum *a, uint64_t n_reads, uint64_t extent, uint32_t flags) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  if (a->held_slot < 0) return fail(QK_ESTATE, "no batch acquired");
+  if (flags & ~QK_BATCH_ALIGNED128) return fail(QK_EINVAL, "unknown flags 0x%x", flags);
+  Slot &s = a->slot[a->held_slot];
+  if (extent > a->cap_bytes || n_reads > a->cap_reads) return fail(QK_EINVAL, "batch exceeds slot capacity");
+  int rc = set_device(a);
+  if (rc) return rc;
+  uint64_t end = 0;
+  uint32_t max_len = 0;
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    if (s.h_off[i] < end) return fail(QK_EINVAL, "read %llu starts inside its predecessor", (unsigned long long)i);
+    if ((flags & QK_BATCH_ALIGNED128) && (s.h_off[i] & 127u)) return fail(QK_EINVAL, "read %llu is not 128-byte aligned", (unsigned long long)i);
+    end = s.h_off[i] + s.h_len[i];
+    max_len = std::max(max_len, s.h_len[i]);
+  }
+  if (end > extent) return fail(QK_EINVAL, "reads end at %llu, past the batch extent", (unsigned long long)end);
+  a->held_slot = -1;
+  a->next_slot ^= 1;
+  if (n_reads == 0) return QK_OK;
+  if ((rc = grow_table(a, std::max<uint64_t>(max_len, 11)))) return rc;
+  memset(s.h_seq + extent, 0, QK_TAIL_SLACK);
+  memset(s.h_qual + extent, 0, QK_TAIL_SLACK);
+  QK_HIP(hipMemcpyAsync(s.d_seq, s.h_seq, extent + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
+  QK_HIP(hipMemcpyAsync(s.d_qual, s.h_qual, extent + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
+  QK_HIP(hipMemcpyAsync(s.d_off, s.h_off, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s.stream));
+  QK_HIP(hipMemcpyAsync(s.d_len, s.h_len, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
+  rc = enqueue_batch(a, s.d_seq, s.d_qual, s.d_off, s.d_hit, n_reads, extent, max_len, s.stream, s.d_len, flags);
+  if (rc) return rc;
+  QK_HIP(hipEventRecord(s.done, s.stream));
+  s.busy = true;
+  return QK_OK;
+}
+
 int qk_accum_sync(qk_accum *a) {
   if (!a) return fail(QK_EINVAL, "acc is NULL");
   int rc = set_device(a);
@@ -695,6 +794,15 @@ int qk_accum_sync(qk_accum *a) {
       if (a->slot[i].stream) QK_HIP(hipStreamSynchronize(a->slot[i].stream));
   }
   for (int i = 0; i < 2; ++i) a->slot[i].busy = false;
+  if (a->status_armed) {
+    uint32_t st = 0;
+    QK_HIP(hipMemcpy(&st, a->d_status, sizeof st, hipMemcpyDeviceToHost));
+    a->status_armed = false;
+    if (st) {
+      QK_HIP(hipMemset(a->d_status, 0, sizeof st));
+      return fail(QK_EINVAL, "a batch submitted as QK_BATCH_ALIGNED128 holds a read that does not start on a 128-byte boundary; the counters are unusable");
+    }
+  }
   return drain_timing(a);
 }
 

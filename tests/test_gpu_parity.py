@@ -194,6 +194,72 @@ def test_many_submits_and_table_growth():
     assert_same((sd.bases, sd.number_of_sequences), ob.accumulate_batch(seq, qual, off))
 
 
+# ------------------------------------------------------------ gapped batches
+def gapped(seq, qual, off, align, seed):
+    """same reads, but every read starts on an `align`-byte boundary (align=0: after
+    a random gap of 0..300 bytes); the gaps hold bytes that would count if touched"""
+    g = np.random.default_rng(seed)
+    lens = np.diff(off.astype(np.int64))
+    starts, pos = np.zeros(len(lens), np.int64), 0
+    for r, l in enumerate(lens):
+        pos = (pos + align - 1) // align * align if align else pos + int(g.integers(0, 301))
+        starts[r] = pos
+        pos += int(l)
+    gs = g.choice(np.frombuffer(b"ACGT", np.uint8), pos).astype(np.uint8)
+    gq = g.integers(35, 70, pos).astype(np.uint8)
+    for r, l in enumerate(lens):
+        gs[starts[r]:starts[r] + l] = seq[int(off[r]):int(off[r + 1])]
+        gq[starts[r]:starts[r] + l] = qual[int(off[r]):int(off[r + 1])]
+    return gs, gq, starts.astype(np.uint64), lens.astype(np.uint32)
+
+
+def hip_gapped(gs, gq, starts, lens, aligned, bits, device):
+    import torch
+    with quack_amd.Accumulator(0, bits) as acc:
+        if device:
+            d = [torch.from_numpy(pad_for_device(gs)).cuda(), torch.from_numpy(pad_for_device(gq)).cuda(),
+                 torch.from_numpy(starts.astype(np.int64)).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda()]
+            acc.submit_device_gapped(d[0], d[1], d[2], d[3], len(lens), len(gs), int(lens.max()), aligned=aligned)
+        else:
+            acc.submit_gapped(gs, gq, starts, lens, aligned=aligned)
+        sd = acc.finish()
+    return sd.bases, sd.number_of_sequences
+
+
+@pytest.mark.parametrize("shape", ["long", "long_adapters", "short", "mixed_adapters"])
+def test_gapped_and_cache_line_aligned_batches(shape):
+    """reads separated by gaps (QK_BATCH_ALIGNED128: on cache lines — the layout
+    the host feed gives long reads) count exactly like the packed batch"""
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads) if "adapters" in shape else None
+    bits = ob.kmers_to_bitset(k) if k is not None else None
+    n, lo, hi = {"long": (600, 1000, 20000), "long_adapters": (400, 500, 9000), "short": (20000, 1, 150),
+                 "mixed_adapters": (3000, 1, 2500)}[shape]
+    seq, qual, off = synth.ragged(n, lo, hi, seed=hi)
+    if k is not None:
+        rng = np.random.default_rng(3)
+        for r in rng.integers(0, n, n // 2):
+            a, b = int(off[r]), int(off[r + 1])
+            ad = np.frombuffer(ads[int(rng.integers(0, len(ads)))], np.uint8)
+            at = a + int(rng.integers(0, max(1, b - a)))
+            m = min(len(ad), b - at)
+            seq[at:at + m] = ad[:m]
+    want = ob.accumulate_batch(seq, qual, off, kmers=k)
+    for align, aligned in ((128, True), (128, False), (0, False), (8, False)):
+        gs, gq, starts, lens = gapped(seq, qual, off, align, seed=align)
+        for device in (True, False):
+            assert_same(hip_gapped(gs, gq, starts, lens, aligned, bits, device), want)
+
+
+def test_a_false_alignment_promise_is_detected():
+    seq, qual, off = synth.ragged(300, 2000, 9000, seed=77)
+    gs, gq, starts, lens = gapped(seq, qual, off, 0, seed=1)          # random gaps: not on cache lines
+    with pytest.raises(quack_amd.HipUnavailable, match="128"):
+        hip_gapped(gs, gq, starts, lens, True, None, device=True)       # found by the kernel, reported at finish
+    with pytest.raises(quack_amd.HipUnavailable, match="128"):
+        hip_gapped(gs, gq, starts, lens, True, None, device=False)      # found by the host check at commit
+
+
 def test_submits_from_several_streams_into_one_accumulator():
     """device-resident batches enqueued from three streams, un-synchronised, with
     pinned-slot batches in between: launches of one accumulator share its work
