@@ -42,8 +42,12 @@ WORKLOADS = {
                  label="10M-read synthetic 150 bp FASTQ, no adapters (BASELINE.json configs[1])"),
     "cfg3": dict(n=10_000_000, L=300, ragged=None, adapters=True,
                  label="10M-read synthetic 300 bp FASTQ + adapter FASTA (configs[2])"),
-    "cfg5": dict(n=143_000, L=20000, ragged=(1000, 20000), adapters=False,
-                 label="PacBio-style ragged 1-20 kb synthetic FASTQ (configs[4])"),
+    # long reads live in HBM the way the host feed lays them out (pipeline.c): every read starts on a
+    # 128-byte cache line (QK_BATCH_ALIGNED128); cfg5packed = the same reads without the padding
+    "cfg5": dict(n=143_000, L=20000, ragged=(1000, 20000), adapters=False, aligned=True,
+                 label="PacBio-style ragged 1-20 kb synthetic FASTQ, reads on 128-B lines as the host feed lays them out (configs[4])"),
+    "cfg5packed": dict(n=143_000, L=20000, ragged=(1000, 20000), adapters=False,
+                 label="PacBio-style ragged 1-20 kb synthetic FASTQ, packed (configs[4])"),
     # configs[3]: paired 2 x 50M x 150 bp over 8 GPUs -> per GPU 2 x 6.25M reads; the two mates are two
     # independent accumulations (quack.c:911-921); R2 qualities skewed lower
     "cfg4": dict(n=6_250_000, L=150, ragged=None, adapters=False, paired=True,
@@ -57,18 +61,27 @@ def make_batch(w, seed, device, quality="uniform", q_hi_override=None):
     if w["ragged"]:
         rng = np.random.default_rng(seed)
         lens = rng.integers(w["ragged"][0], w["ragged"][1] + 1, w["n"])
-        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        total, max_len = int(off[-1]), int(lens.max())
-        d_off = torch.from_numpy(off).to(device)
+        d_len = None
+        if w.get("aligned"):
+            starts = np.concatenate([[0], np.cumsum((lens + 127) // 128 * 128)]).astype(np.int64)
+            extent = int(starts[-2] + lens[-1])
+            d_off = torch.from_numpy(starts[:-1].copy()).to(device)
+            d_len = torch.from_numpy(lens.astype(np.int32)).to(device)
+        else:
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            extent = int(off[-1])
+            d_off = torch.from_numpy(off).to(device)
+        total, max_len = int(lens.sum()), int(lens.max())
         q_lo, q_hi = 1, 60
     else:
-        total, max_len, d_off = w["n"] * w["L"], w["L"], None
+        total, max_len, d_off, d_len = w["n"] * w["L"], w["L"], None, None
+        extent = total
         q_lo, q_hi = 2, (q_hi_override or 41)
-    seq = torch.zeros(total + 16, dtype=torch.uint8, device=device)
-    qual = torch.zeros(total + 16, dtype=torch.uint8, device=device)
+    seq = torch.zeros(extent + 16, dtype=torch.uint8, device=device)
+    qual = torch.zeros(extent + 16, dtype=torch.uint8, device=device)
     step = 1 << 28
-    for a in range(0, total, step):
-        b = min(total, a + step)
+    for a in range(0, extent, step):   # (the padding between aligned reads holds letters and scores too: never counted)
+        b = min(extent, a + step)
         seq[a:b] = lut[torch.randint(0, 4, (b - a,), generator=g, device=device)]
         if quality == "novaseq4":
             levels = torch.tensor([33 + 2, 33 + 12, 33 + 23, 33 + 37], dtype=torch.uint8, device=device)
@@ -77,7 +90,7 @@ def make_batch(w, seed, device, quality="uniform", q_hi_override=None):
             qual[a:b] = levels[idx]
         else:
             qual[a:b] = (33 + torch.randint(q_lo, q_hi + 1, (b - a,), generator=g, device=device)).to(torch.uint8)
-    return seq, qual, d_off, total, max_len
+    return seq, qual, d_off, total, max_len, d_len, extent
 
 
 def synthetic_adapter_bits(seed=3):
@@ -96,7 +109,7 @@ def synthetic_adapter_bits(seed=3):
     return bits, ads
 
 
-def cpu_baseline(seq, qual, d_off, n, total, w, ads):
+def cpu_baseline(seq, qual, d_off, n, total, w, ads, d_len=None):
     """oracle on one host core over (a bounded sample of) the same batch"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
@@ -110,9 +123,20 @@ def cpu_baseline(seq, qual, d_off, n, total, w, ads):
         dt = time.perf_counter() - t0
         bases, sample = m * w["L"], "%d of %d reads x %d bp (same bytes as the GPU batch)" % (m, n, w["L"])
     else:
-        off = d_off.cpu().numpy().astype(np.uint64)
-        m = int(min(n, np.searchsorted(off, budget_bases)))
-        hs, hq = seq[:int(off[m])].cpu().numpy(), qual[:int(off[m])].cpu().numpy()
+        if d_len is not None:   # gapped on the device: the oracle takes the same reads packed
+            starts, lens = d_off.cpu().numpy().astype(np.int64), d_len.cpu().numpy().astype(np.int64)
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+            m = int(min(n, np.searchsorted(off, budget_bases)))
+            end = int(starts[m - 1] + lens[m - 1])
+            gs, gq = seq[:end].cpu().numpy(), qual[:end].cpu().numpy()
+            keep = np.zeros(end, dtype=bool)
+            for a, l in zip(starts[:m], lens[:m]):
+                keep[a:a + l] = True
+            hs, hq = gs[keep], gq[keep]
+        else:
+            off = d_off.cpu().numpy().astype(np.uint64)
+            m = int(min(n, np.searchsorted(off, budget_bases)))
+            hs, hq = seq[:int(off[m])].cpu().numpy(), qual[:int(off[m])].cpu().numpy()
         t0 = time.perf_counter()
         ob.accumulate_batch(hs, hq, off[:m + 1], kmers=kmers)
         dt = time.perf_counter() - t0
@@ -156,15 +180,15 @@ def main():
     if args.reads:
         w["n"] = args.reads
     bits, ads = synthetic_adapter_bits() if w["adapters"] else (None, None)
-    seq, qual, d_off, total, max_len = make_batch(w, seed=2 + rank, device=device, quality=args.quality)
+    seq, qual, d_off, total, max_len, d_len, extent = make_batch(w, seed=2 + rank, device=device, quality=args.quality)
     n = w["n"]
-    alg_bytes = 2.0 * total + (8.0 * n if d_off is not None else 0.0)
+    alg_bytes = 2.0 * total + ((12.0 if d_len is not None else 8.0) * n if d_off is not None else 0.0)
 
     acc = quack_amd.Accumulator(local, bits, max_len_hint=max_len)
     mate = None
     if w.get("paired"):
         # the reverse mate: its own batch and its own accumulator
-        seq2, qual2, _, _, _ = make_batch(w, seed=1000 + rank, device=device, quality=args.quality, q_hi_override=30)
+        seq2, qual2, _, _, _, _, _ = make_batch(w, seed=1000 + rank, device=device, quality=args.quality, q_hi_override=30)
         mate = quack_amd.Accumulator(local, bits, max_len_hint=max_len)
 
     # paired: both mates on ONE stream, so that every launch has the GPU to itself and its
@@ -173,7 +197,10 @@ def main():
     shared_stream = side.cuda_stream if side is not None else None
 
     def step():
-        acc.submit_device(seq, qual, d_off, n, total, max_len, stream=shared_stream)
+        if d_len is not None:
+            acc.submit_device_gapped(seq, qual, d_off, d_len, n, extent, max_len, aligned=True, stream=shared_stream)
+        else:
+            acc.submit_device(seq, qual, d_off, n, total, max_len, stream=shared_stream)
         if mate is not None:
             mate.submit_device(seq2, qual2, None, n, total, max_len, stream=shared_stream)
 
@@ -250,7 +277,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seq, qual, d_off, n, total, w, ads)
+            out["cpu_baseline"] = cpu_baseline(seq, qual, d_off, n, total, w, ads, d_len)
         print(json.dumps(out), flush=True)
     acc.close()
     if mate is not None:
