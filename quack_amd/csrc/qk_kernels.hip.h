@@ -481,6 +481,21 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
       // One step = RW*U reads: `issue` computes the addresses and starts the
       // loads, `consume` histograms them.  With PD > 1 the loads of step k+1
       // are in flight while step k is consumed (PD register sets).
+      // Ragged: the descriptors of a step are read from the staged list one step
+      // AHEAD (load_desc, right after the previous step's loads went out and
+      // before its ds_adds), so that the LDS read does not queue behind a
+      // step's 32 atomics when the next global loads want to start.
+      uint2 de[U];
+      uint32_t dr[U];
+      auto load_desc = [&](uint32_t it) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t rel = it + (uint32_t)u * RW + ri;
+          const bool in_list = rel < n_list && ri < RW;
+          de[u] = lds_list[in_list ? rel : 0u];
+          dr[u] = ADAPT ? lds_ridx[in_list ? rel : 0u] : 0u;
+        }
+      };
       auto issue = [&](uint32_t it, u32x3 (&q)[U], u32x3 (&s)[U], uint32_t (&nv)[U], uint32_t (&sk)[U],
                        uint32_t (&ridx)[U]) __attribute__((always_inline)) {
 #pragma unroll
@@ -493,10 +508,10 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
             len = p.read_len;
             ridx[u] = rel;
           } else {
-            const uint2 e = lds_list[in_list ? rel : 0u];
+            const uint2 e = PD > 1 ? lds_list[in_list ? rel : 0u] : de[u];
             off = e.x + cpos;
             len = e.y;
-            ridx[u] = ADAPT ? pass + lds_ridx[in_list ? rel : 0u] : 0u;
+            ridx[u] = ADAPT ? pass + (PD > 1 ? lds_ridx[in_list ? rel : 0u] : dr[u]) : 0u;
           }
           // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
           // compute codes like their originals but count nothing
@@ -695,10 +710,12 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           }
         }
       } else {
+        if (!FIXED) load_desc(0u);
         for (uint32_t it = 0; it < n_list; it += RW * U) {
           u32x3 q[U], s[U];
           uint32_t nv[U], sk[U], ridx[U];
           issue(it, q, s, nv, sk, ridx);
+          if (!FIXED) load_desc(it + RW * U);
           consume(q, s, nv, sk, ridx);
         }
       }
