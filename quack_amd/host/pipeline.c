@@ -41,7 +41,7 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
                         uint64_t *n_reads) {
   qk_accum *accs[64];
   qkh_reader *rd = NULL;
-  int rc = -1, turn = 0, made = 0;
+  int rc = -1, turn = 0, made = 0, long_reads = 0;
   const int verbose = getenv("QUACK_VERBOSE") != NULL;
   const double t0 = now_s();
   double t_created, t_first = 0, t_parsed;
@@ -71,16 +71,30 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       goto out;
     }
     if (!t_first) t_first = now_s();
-    n = qkh_reader_fill(rd, seq, qual, offsets, cap_bytes, cap_reads, &total, &uniform);
+    if (long_reads) {
+      /* long reads (judged by the previous batch): every read starts on a 128-byte
+       * cache line, so that the position tiles the kernels cut them into are whole
+       * lines (QK_BATCH_ALIGNED128, quack_hip.h); costs < 64 bytes of padding per read */
+      uint32_t *lengths;
+      if (qk_accum_slot_lengths(acc, &lengths)) {
+        host_fail("%s", qk_last_error());
+        goto out;
+      }
+      n = qkh_reader_fill_gapped(rd, seq, qual, offsets, lengths, cap_bytes, cap_reads, 128, &total, &uniform);
+    } else {
+      n = qkh_reader_fill(rd, seq, qual, offsets, cap_bytes, cap_reads, &total, &uniform);
+    }
     if (n < 0) {
       host_fail(n == -4 ? "%s: a read exceeds the batch size (raise QUACK_HIP_BATCH_MB)"
                         : "%s: out of memory while parsing", path);
       goto out;
     }
-    if (qk_accum_commit(acc, (uint64_t)n, total, uniform == 0, uniform)) {
+    if (long_reads ? qk_accum_commit_gapped(acc, (uint64_t)n, total, QK_BATCH_ALIGNED128)
+                   : qk_accum_commit(acc, (uint64_t)n, total, uniform == 0, uniform)) {
       host_fail("%s", qk_last_error());
       goto out;
     }
+    if (n > 0) long_reads = total / (uint64_t)n >= 1024 && !getenv("QUACK_NO_ALIGN");
     turn = (turn + 1) % n_devices;
   }
   t_parsed = now_s();

@@ -38,6 +38,14 @@ int64_t qkh_reader_fill(qkh_reader *r, uint8_t *seq, uint8_t *qual,
                         uint64_t *offsets, uint64_t cap_bytes,
                         uint64_t cap_reads, uint64_t *total_bytes,
                         uint32_t *uniform_len);
+/* Same, into a gapped batch (qk_accum_commit_gapped): read i starts at
+ * starts[i], a multiple of `align` (a power of two; 128 = one HBM cache line,
+ * QK_BATCH_ALIGNED128), and is lengths[i] long; *extent_bytes is the end of the
+ * last read.  The bytes between reads are left as they are. */
+int64_t qkh_reader_fill_gapped(qkh_reader *r, uint8_t *seq, uint8_t *qual,
+                               uint64_t *starts, uint32_t *lengths, uint64_t cap_bytes,
+                               uint64_t cap_reads, uint64_t align,
+                               uint64_t *extent_bytes, uint32_t *uniform_len);
 /* 1 once the stream is exhausted (or stopped by a malformed record) */
 int qkh_reader_done(const qkh_reader *r);
 

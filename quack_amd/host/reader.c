@@ -189,26 +189,31 @@ void qkh_reader_close(qkh_reader *r) {
 
 int qkh_reader_done(const qkh_reader *r) { return r->finished && !r->have_parked; }
 
-int64_t qkh_reader_fill(qkh_reader *r, uint8_t *seq, uint8_t *qual,
-                        uint64_t *offsets, uint64_t cap_bytes,
-                        uint64_t cap_reads, uint64_t *total_bytes,
-                        uint32_t *uniform_len) {
-  uint64_t n = 0, total = 0;
-  int64_t common = -1;   /* -1 unknown, -2 mixed */
-  offsets[0] = 0;
+/* One batch.  Read i is written at starts[i], the end of its predecessor
+ * rounded up to `align`; lengths may be NULL (packed batches: the caller reads
+ * the ends off the next start). */
+static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *starts, uint32_t *lengths,
+                          uint64_t cap_bytes, uint64_t cap_reads, uint64_t align, uint64_t *extent,
+                          uint32_t *uniform_len) {
+  uint64_t n = 0, total = 0;   /* total = end of the last read */
+  int64_t common = -1;         /* -1 unknown, -2 mixed */
   if (r->have_parked) {
     if (r->park_len > cap_bytes) return -4;   /* a single read exceeds the batch */
     memcpy(seq, r->park_seq, r->park_len);
     if (r->parked_is_fastq) memcpy(qual, r->park_qual, r->park_len);
     else memset(qual, 0, r->park_len);
+    starts[0] = 0;
+    if (lengths) lengths[0] = (uint32_t)r->park_len;
     total = r->park_len;
-    offsets[++n] = total;
+    n = 1;
     common = (int64_t)r->park_len;
     r->have_parked = 0;
   }
   while (!r->finished && n < cap_reads) {
-    sink sq = {seq + total, 0, cap_bytes - total, &r->park_seq, &r->park_seq_cap, 0};
-    sink ql = {qual + total, 0, cap_bytes - total, &r->park_qual, &r->park_qual_cap, 0};
+    const uint64_t at = (total + align - 1) & ~(align - 1);
+    if (at >= cap_bytes && n > 0) break;      /* no room left for another start */
+    sink sq = {seq + at, 0, cap_bytes - at, &r->park_seq, &r->park_seq_cap, 0};
+    sink ql = {qual + at, 0, cap_bytes - at, &r->park_qual, &r->park_qual_cap, 0};
     int is_fastq = 0;
     long l = parse_record(r, &sq, &ql, &is_fastq);
     if (l == -3) return -3;
@@ -226,15 +231,39 @@ int64_t qkh_reader_fill(qkh_reader *r, uint8_t *seq, uint8_t *qual,
       if (n == 0 && (uint64_t)l > cap_bytes) return -4;
       break;
     }
-    if (!is_fastq) memset(qual + total, 0, (size_t)l);  /* FASTA fed as reads: no scores */
-    total += (uint64_t)l;
-    offsets[++n] = total;
+    if (!is_fastq) memset(qual + at, 0, (size_t)l);  /* FASTA fed as reads: no scores */
+    starts[n] = at;
+    if (lengths) {
+      if ((uint64_t)l > 0xFFFFFFFFull) return -4;
+      lengths[n] = (uint32_t)l;
+    }
+    n++;
+    total = at + (uint64_t)l;
     if (common == -1) common = l;
     else if (common != l) common = -2;
   }
-  *total_bytes = total;
+  *extent = total;
   *uniform_len = (common > 0 && common <= 0x7FFFFFFF) ? (uint32_t)common : 0;
   return (int64_t)n;
+}
+
+int64_t qkh_reader_fill(qkh_reader *r, uint8_t *seq, uint8_t *qual,
+                        uint64_t *offsets, uint64_t cap_bytes,
+                        uint64_t cap_reads, uint64_t *total_bytes,
+                        uint32_t *uniform_len) {
+  int64_t n;
+  offsets[0] = 0;
+  n = fill_batch(r, seq, qual, offsets, NULL, cap_bytes, cap_reads, 1, total_bytes, uniform_len);
+  if (n >= 0) offsets[n] = *total_bytes;   /* packed: read i ends where i+1 starts */
+  return n;
+}
+
+int64_t qkh_reader_fill_gapped(qkh_reader *r, uint8_t *seq, uint8_t *qual,
+                               uint64_t *starts, uint32_t *lengths, uint64_t cap_bytes,
+                               uint64_t cap_reads, uint64_t align,
+                               uint64_t *extent_bytes, uint32_t *uniform_len) {
+  if (!align || (align & (align - 1)) || !lengths) return -3;
+  return fill_batch(r, seq, qual, starts, lengths, cap_bytes, cap_reads, align, extent_bytes, uniform_len);
 }
 
 /* ----------------------------------------------------------------- adapters */

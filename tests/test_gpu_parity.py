@@ -310,6 +310,31 @@ def test_pinned_pipeline_many_small_batches(monkeypatch):
     assert_same(hip_table(seq, qual, read_len=150), ob.accumulate_batch(seq, qual, read_len=150))
 
 
+def test_host_feed_pads_long_reads_onto_cache_lines(tmp_path, monkeypatch):
+    """whole-file path on long reads: from the second batch on the tokenizer writes every
+    read at a 128-byte boundary (QK_BATCH_ALIGNED128); same counters as the oracle, as
+    the unpadded feed, and through three accumulators"""
+    monkeypatch.setenv("QUACK_HIP_BATCH_MB", "2")
+    seq, qual, off = synth.ragged(900, 800, 12000, seed=5)         # ~5.8 MB of reads: several batches
+    fq = tmp_path / "long.fq"
+    with open(fq, "wb") as f:
+        for r in range(len(off) - 1):
+            a, b = int(off[r]), int(off[r + 1])
+            f.write(b"@r%d\n" % r + seq[a:b].tobytes() + b"\n+\n" + qual[a:b].tobytes() + b"\n")
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    for kmers, bits in ((None, None), (k, ob.kmers_to_bitset(k))):
+        want = ob.accumulate_batch(seq, qual, off, kmers=kmers)
+        sd = quack_amd.read_fastq(str(fq), bits)
+        assert_same((sd.bases, sd.number_of_sequences), want)
+        sd3 = quack_amd.read_fastq(str(fq), bits, devices=(0, 0, 0))
+        assert_same((sd3.bases, sd3.number_of_sequences), want)
+        monkeypatch.setenv("QUACK_NO_ALIGN", "1")
+        sd = quack_amd.read_fastq(str(fq), bits)
+        monkeypatch.delenv("QUACK_NO_ALIGN")
+        assert_same((sd.bases, sd.number_of_sequences), want)
+
+
 @pytest.mark.parametrize("cfg", [dict(threads=512, unroll=2, tile=96, wgs_per_cu=4),
                                  dict(threads=256, unroll=4, tile=64, wgs_per_cu=8),
                                  dict(threads=1024, unroll=1, tile=304, wgs_per_cu=1),
