@@ -457,6 +457,31 @@ int qk_debug_set_mode(int mode) {
   return QK_OK;
 }
 
+// Launch geometry for a batch shape, without a device (tests/test_planner.py
+// checks the invariants the kernels rely on over many shapes).
+int qk_debug_plan(uint64_t n_reads, uint32_t max_len, int ragged, int adapters, uint32_t bucket_log2,
+                  int gapped, int aligned, int n_cu, uint64_t *out /* [16] */) {
+  if (!out) return fail(QK_EINVAL, "out is NULL");
+  qk_accum a;
+  a.n_cu = n_cu > 0 ? n_cu : 256;
+  a.adapters = adapters != 0;
+  a.bucket_log2 = adapters ? bucket_log2 : 0;
+  a.threads = env_int("QUACK_HIP_THREADS", a.threads);
+  a.unroll = env_int("QUACK_HIP_UNROLL", a.unroll);
+  a.pipe = env_int("QUACK_HIP_PIPE", a.pipe);
+  a.tile = env_int("QUACK_HIP_TILE", a.tile);
+  a.wgs_per_cu = env_int("QUACK_HIP_WGS_PER_CU", a.wgs_per_cu);
+  Plan pl;
+  int rc = make_plan(&a, n_reads, max_len, ragged != 0, gapped != 0, aligned != 0, &pl);
+  if (rc) return rc;
+  out[0] = pl.n_tiles; out[1] = pl.tile_pos; out[2] = pl.ch; out[3] = pl.rw;
+  out[4] = (uint64_t)pl.unroll; out[5] = (uint64_t)pl.pipe; out[6] = pl.reads_per_slice; out[7] = pl.n_slices;
+  out[8] = pl.n_blocks; out[9] = qk::hist_lds_bytes(pl.ch, pl.fused_adapters, pl.bucket_log2, ragged != 0);
+  out[10] = pl.halo; out[11] = pl.fused_adapters; out[12] = pl.dynamic; out[13] = pl.aligned;
+  out[14] = qk::hist_replicas(pl.ch, pl.fused_adapters); out[15] = qk::hist_row_dwords(pl.ch, pl.fused_adapters);
+  return QK_OK;
+}
+
 int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
                     uint64_t max_len_hint) {
   if (!out) return fail(QK_EINVAL, "out is NULL");

@@ -1,0 +1,60 @@
+"""Launch planner (qk_shim.hip: make_plan) — host logic, no GPU needed: the
+invariants the kernels rely on, over a sweep of batch shapes."""
+import ctypes
+import itertools
+
+import pytest
+
+from quack_amd import _capi
+
+L = _capi.hip()
+L.qk_debug_plan.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
+                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+KEYS = ("n_tiles tile_pos ch rw unroll pipe reads_per_slice n_slices n_blocks lds halo fused dynamic aligned "
+        "replicas row_dwords").split()
+
+
+def plan(n_reads, max_len, ragged=False, adapters=False, bucket_log2=10, gapped=False, aligned=False, n_cu=256):
+    out = (ctypes.c_uint64 * 16)()
+    rc = L.qk_debug_plan(n_reads, max_len, ragged, adapters, bucket_log2, gapped, aligned, n_cu, out)
+    if rc:
+        raise RuntimeError(L.qk_last_error().decode())
+    return dict(zip(KEYS, out))
+
+
+LENGTHS = [1, 7, 8, 9, 36, 40, 50, 56, 57, 64, 72, 76, 80, 81, 88, 100, 150, 151, 250, 300, 304, 448, 449, 512, 576,
+           577, 1000, 4096, 10500, 20000, 100000, 3_000_000]
+
+
+@pytest.mark.parametrize("ragged,adapters", list(itertools.product([False, True], [False, True])))
+def test_plans_fit_the_hardware(ragged, adapters):
+    for max_len, n_reads, blog in itertools.product(LENGTHS, [1, 1000, 10_000_000, 3_000_000_000 // 150], [0, 6, 10]):
+        if n_reads * max_len > 1 << 36:
+            continue
+        p = plan(n_reads, max_len, ragged, adapters, blog)
+        ctx = (max_len, n_reads, ragged, adapters, blog, p)
+        assert p["lds"] <= 160 * 1024, ctx                                  # one workgroup's LDS
+        assert p["tile_pos"] == 8 * p["ch"] and p["n_tiles"] * p["tile_pos"] >= max_len, ctx
+        assert (p["n_tiles"] - 1) * p["tile_pos"] < max_len, ctx            # no empty tile
+        lanes = 1024 // 64 * 62 if p["fused"] else 1024
+        assert p["rw"] >= 1 and p["rw"] * (p["ch"] + p["halo"]) <= lanes, ctx
+        step = p["rw"] * p["unroll"]
+        assert p["reads_per_slice"] % step == 0 and p["reads_per_slice"] + step <= 65535, ctx   # u16 LDS counters
+        assert p["n_slices"] * p["reads_per_slice"] >= n_reads, ctx          # every read belongs to a slice
+        assert p["reads_per_slice"] * max_len <= 0x7FFFFFFF or max_len > 0x7FFFFFFF // step, ctx  # 32-bit offsets
+        assert p["row_dwords"] % 32 == 0 and p["row_dwords"] >= 4 * p["replicas"] * p["ch"], ctx  # bank == column
+        assert p["dynamic"] == (p["n_tiles"] > 1), ctx
+        assert p["n_blocks"] >= 1 and (p["dynamic"] or p["n_blocks"] == p["n_slices"]), ctx
+        assert (p["unroll"], p["pipe"]) == ((4, 1) if ragged else ((4, 2) if adapters else (1, 2))), ctx
+        assert not p["aligned"]
+
+
+def test_cache_line_plans():
+    for max_len in (600, 1000, 5000, 20000, 100000):
+        for adapters in (False, True):
+            p = plan(100000, max_len, ragged=True, adapters=adapters, gapped=True, aligned=True)
+            assert p["aligned"] and p["tile_pos"] % 128 == 0 and p["n_tiles"] > 1 and p["lds"] <= 160 * 1024, (max_len, p)
+    p = plan(100000, 150, ragged=True, gapped=True, aligned=True)       # one tile: nothing to align
+    assert not p["aligned"] and p["n_tiles"] == 1
+    with pytest.raises(RuntimeError):
+        plan(10, 0xFFFFFFF0, ragged=True)                                # a read that no slice can address
