@@ -251,6 +251,32 @@ def test_gapped_and_cache_line_aligned_batches(shape):
             assert_same(hip_gapped(gs, gq, starts, lens, aligned, bits, device), want)
 
 
+def test_gapped_edge_cases():
+    """empty batch, a single read, zero-length reads between long ones, reads that end
+    exactly on a tile / cache-line boundary"""
+    import torch
+    with quack_amd.Accumulator(0) as acc:                                  # nothing at all
+        z8, z64, z32 = torch.zeros(16, dtype=torch.uint8).cuda(), torch.zeros(1, dtype=torch.int64).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+        acc.submit_device_gapped(z8, z8, z64, z32, 0, 0, 0, aligned=True)
+        acc.submit_gapped(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(0, np.uint64), np.zeros(0, np.uint32), aligned=True)
+        sd = acc.finish()
+        assert sd.number_of_sequences == 0 and sd.bases.shape[0] == 0
+    lens = np.array([0, 512, 0, 1024, 1, 128, 4096, 0, 511, 513, 2000, 0], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    g = np.random.default_rng(8)
+    seq = g.choice(np.frombuffer(b"ACGT", np.uint8), int(off[-1])).astype(np.uint8)
+    qual = g.integers(33, 75, int(off[-1])).astype(np.uint8)
+    want = ob.accumulate_batch(seq, qual, off)
+    for align, aligned in ((128, True), (0, False)):
+        gs, gq, starts, ln = gapped(seq, qual, off, align, seed=2)
+        for device in (True, False):
+            assert_same(hip_gapped(gs, gq, starts, ln, aligned, None, device), want)
+    one = off[3:5] - off[3]
+    assert_same(hip_gapped(seq[int(off[3]):int(off[4])], qual[int(off[3]):int(off[4])], np.zeros(1, np.uint64),
+                           np.array([1024], np.uint32), True, None, True),
+                ob.accumulate_batch(seq[int(off[3]):int(off[4])], qual[int(off[3]):int(off[4])], one.astype(np.uint64)))
+
+
 def test_a_false_alignment_promise_is_detected():
     seq, qual, off = synth.ragged(300, 2000, 9000, seed=77)
     gs, gq, starts, lens = gapped(seq, qual, off, 0, seed=1)          # random gaps: not on cache lines
