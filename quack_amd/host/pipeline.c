@@ -48,13 +48,14 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
   *bases_out = NULL;
   *max_len = *n_reads = 0;
   if (n_devices < 1 || n_devices > 64) return host_fail("bad device count %d", n_devices);
-  /* the producer threads start inflating now, while HIP initialises below */
-  rd = qkh_reader_open(path);
   for (; made < n_devices; made++)
     if (qk_accum_create(&accs[made], devices[made], bitset, 0)) {
       host_fail("device %d: %s", devices[made], qk_last_error());
       goto out;
     }
+  /* (opening the reader first, so that inflate overlaps HIP's start-up, was measured:
+   * no gain — the tokenizer, not inflate, paces the file) */
+  rd = qkh_reader_open(path);
   if (!rd) {
     host_fail("cannot open %s", path);
     goto out;
