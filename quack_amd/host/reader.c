@@ -139,9 +139,22 @@ static long parse_record(qkh_reader *r, sink *sq, sink *ql, int *is_fastq) {
     if (c < 0) return -1;
     r->marker = c;
   }
-  c = skip_name(r);
-  if (c < 0) return -1;
-  if (c != '\n' && c != 0 && take_line(r, NULL) < 0) return -3;
+  /* Header line.  The name ends at the first whitespace; if that is not the
+   * newline the rest of the line is skipped as well — either way the parser
+   * ends up just behind the first '\n', so when one is in sight a memchr does
+   * the whole line (Illumina headers are 40-70 bytes: the per-byte scan of
+   * skip_name was a fifth of the tokenizer's time).  The careful path below
+   * only sees lines cut by a block boundary or by the end of the stream. */
+  {
+    const uint8_t *nl = r->pos < r->lim ? memchr(r->buf + r->pos, '\n', r->lim - r->pos) : NULL;
+    if (nl) {
+      r->pos = (size_t)(nl - r->buf) + 1;
+    } else {
+      c = skip_name(r);
+      if (c < 0) return -1;
+      if (c != '\n' && c != 0 && take_line(r, NULL) < 0) return -3;
+    }
+  }
   for (;;) {
     uint8_t first;
     c = next_byte(r);
@@ -157,8 +170,15 @@ static long parse_record(qkh_reader *r, sink *sq, sink *ql, int *is_fastq) {
     r->marker = 0;
     return (long)sq->len;
   }
-  do c = next_byte(r); while (c >= 0 && c != '\n');
-  if (c < 0) return -2;
+  {  /* rest of the '+' line */
+    const uint8_t *nl = r->pos < r->lim ? memchr(r->buf + r->pos, '\n', r->lim - r->pos) : NULL;
+    if (nl) {
+      r->pos = (size_t)(nl - r->buf) + 1;
+    } else {
+      do c = next_byte(r); while (c >= 0 && c != '\n');
+      if (c < 0) return -2;
+    }
+  }
   for (;;) {
     int got = take_line(r, ql);
     if (got < 0) return -3;
@@ -189,6 +209,42 @@ void qkh_reader_close(qkh_reader *r) {
 
 int qkh_reader_done(const qkh_reader *r) { return r->finished && !r->have_parked; }
 
+/* The common case without the general machinery: a four-line FASTQ record
+ * (header / one sequence line / '+' line / one quality line of the same
+ * length, no CR) that lies completely inside the current block and fits the
+ * batch.  Copies it and returns its length, or returns 0 having consumed
+ * nothing — every other shape (multi-line, FASTA, CRLF, empty lines, records
+ * cut by a block boundary, parked records, the end of the stream) is left to
+ * parse_record, which gives the same answer for these. */
+static size_t fast_record(qkh_reader *r, uint8_t *seq_dst, uint8_t *qual_dst, size_t room) {
+  const uint8_t *p, *end, *h, *s0, *e1, *e2, *q0;
+  size_t len;
+  if (!r->have_block || r->pos >= r->lim) return 0;
+  p = r->buf + r->pos;
+  end = r->buf + r->lim;
+  if (r->marker) {
+    if (r->marker != '@') return 0;
+  } else {
+    if (*p != '@') return 0;
+    p++;
+  }
+  if (!(h = memchr(p, '\n', (size_t)(end - p)))) return 0;
+  s0 = h + 1;
+  if (s0 >= end || *s0 == '>' || *s0 == '+' || *s0 == '@' || *s0 == '\n') return 0;
+  if (!(e1 = memchr(s0, '\n', (size_t)(end - s0)))) return 0;
+  len = (size_t)(e1 - s0);
+  if (e1[-1] == '\r' || e1 + 1 >= end || e1[1] != '+') return 0;
+  if (!(e2 = memchr(e1 + 1, '\n', (size_t)(end - (e1 + 1))))) return 0;
+  q0 = e2 + 1;
+  if ((size_t)(end - q0) < len + 1 || q0[len] != '\n' || q0[len - 1] == '\r' || memchr(q0, '\n', len)) return 0;
+  if (len > room) return 0;
+  memcpy(seq_dst, s0, len);
+  memcpy(qual_dst, q0, len);
+  r->pos = (size_t)(q0 - r->buf) + len + 1;
+  r->marker = 0;
+  return len;
+}
+
 /* One batch.  Read i is written at starts[i], the end of its predecessor
  * rounded up to `align`; lengths may be NULL (packed batches: the caller reads
  * the ends off the next start). */
@@ -212,6 +268,17 @@ static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *
   while (!r->finished && n < cap_reads) {
     const uint64_t at = (total + align - 1) & ~(align - 1);
     if (at >= cap_bytes && n > 0) break;      /* no room left for another start */
+    const size_t fl = fast_record(r, seq + at, qual + at, cap_bytes - at);
+    if (fl) {
+      if (fl > 0xFFFFFFFFull) return -4;
+      starts[n] = at;
+      if (lengths) lengths[n] = (uint32_t)fl;
+      n++;
+      total = at + fl;
+      if (common == -1) common = (int64_t)fl;
+      else if (common != (int64_t)fl) common = -2;
+      continue;
+    }
     sink sq = {seq + at, 0, cap_bytes - at, &r->park_seq, &r->park_seq_cap, 0};
     sink ql = {qual + at, 0, cap_bytes - at, &r->park_qual, &r->park_qual_cap, 0};
     int is_fastq = 0;
