@@ -17,21 +17,26 @@
 //     lane's chunk alone — measured SQ_LDS_BANK_CONFLICT ~0.  Per base:
 //     v_bfe (byte -> row) + v_mad_u32_u24 (row -> address) + ds_add_u32;
 //   * base content never touches the LDS in the loop: the owner of a position
-//     keeps SWAR byte counters (valid / T / C / G, 4 positions per VGPR) and
-//     spills them every 255 reads.  A = valid - T - C - G at flush time.
-//     (Measured: LDS *instruction issue*, ~7 cycles per ds_add wave-instruction
-//     per CU, is the binding resource, not the LDS array — two atomics per
-//     base cost 2x one.)
-//   * adapter first hit (ADAPT builds, single-tile batches; quack.c:206-217):
-//     the SWAR indicators give 2-bit codes, 8 of them packed per chunk; the 9
-//     predecessor codes come from lanes -1 / -2 by DPP wave_shr:1 (two feeder
-//     lanes per wave re-compute the previous wave's last chunks); each of the 8
-//     windows is tested against an LDS-resident bit filter keyed by its low
-//     bits, and only filter hits consult the exact table (LDS buckets of 15-bit
-//     remainders, or the global 2^20-bit set for huge adapter files);
-//     atomicMin(first_hit[read]).
+//     keeps SWAR byte counters (not-T / not-C / not-G, 4 positions per VGPR) and
+//     spills "events - count" every <= 255 steps.  A = valid - T - C - G at
+//     flush time.  (Measured: LDS *instruction issue*, ~7 cycles per ds_add
+//     wave-instruction per CU, is the binding resource, not the LDS array — two
+//     atomics per base cost 2x one.)
+//   * the step loop (issue = addresses + loads, consume = histogram) is
+//     software-pipelined for fixed-length batches: the loads of step k+1 are in
+//     flight while step k is consumed (template parameter PD).
+//   * adapter first hit (ADAPT builds; quack.c:206-217): the SWAR indicators
+//     give 2-bit codes, 8 of them packed per chunk; the 9 predecessor codes come
+//     from lanes -1 / -2 by DPP wave_shr:1 (two feeder lanes per wave re-compute
+//     the previous wave's last chunks; with several tiles two halo lanes per
+//     read row cover the 16 positions before the tile); each of the 8 windows
+//     probes a two-level bit filter at LDS byte 0, and only what passes both
+//     consults the exact table (LDS buckets of 15-bit remainders, or the global
+//     2^20-bit set for huge adapter files); atomicMin(first_hit[read]).
 //   * long reads: position tiles x read slices; persistent workgroups pull
-//     slices from per-tile device counters and flush only when they change tile.
+//     slices from per-tile device counters and flush only when they change
+//     tile.  Batches whose reads start on 128-byte lines (AL) get tiles of whole
+//     cache lines and aligned 8-byte loads.
 // Quality rows are raw byte values (& 127); the mapping to quack's 91 score
 // bins is applied once, at flush time (histograms are linear, so re-binning
 // afterwards is exact).
