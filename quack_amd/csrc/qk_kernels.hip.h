@@ -60,7 +60,8 @@ struct HistParams {
   const uint64_t *offsets;      // NULL => fixed-length batch; else start of every read (+ the end of the last
                                 //   one when `lengths` is NULL: packed batch, read r ends where r+1 starts)
   const uint32_t *lengths;      // gapped batch: length of every read (NULL: packed)
-  uint32_t *status;             // bit 0 is set when a batch launched as 128-byte aligned is not
+  uint32_t *status;             // bit 0 is set when a batch submitted as 128-byte aligned is not
+  uint32_t check_aligned;       // the batch was submitted as QK_BATCH_ALIGNED128 (whichever variant runs it)
   unsigned long long *table;    // planar [kOutRows][table_len]
   uint32_t *first_hit;          // per-read first adapter hit (ADAPT only)
   const uint32_t *kmer_bits;    // 2^20-bit exact table (ADAPT only)
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
               o0 = obase[pass + i];
               len = lbase ? lbase[pass + i] : (uint32_t)(obase[pass + i + 1] - o0);
             }
-            if (AL && (o0 & 127u) != 0) atomicOr(p.status, 1u);   // the producer's promise does not hold
+            if ((AL || p.check_aligned) && (o0 & 127u) != 0) atomicOr(p.status, 1u);   // the producer's promise does not hold
           }
           if (tile == 0) {   // wave-uniform
             // length_count and the kmers==NULL count (quack.c:215-219), once per read.

@@ -358,7 +358,8 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.offsets = d_off;
   hp.lengths = d_len;
   hp.status = a->d_status;
-  if (pl.aligned) a->status_armed = true;
+  hp.check_aligned = (d_len && (flags & QK_BATCH_ALIGNED128)) ? 1u : 0u;
+  if (hp.check_aligned) a->status_armed = true;
   hp.table = a->d_table;
   hp.first_hit = d_hit;
   hp.kmer_bits = a->d_kmer_bits;

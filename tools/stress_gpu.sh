@@ -1,0 +1,13 @@
+#!/bin/bash
+# Run ON THE GPU BOX: the parity suite again under launch geometries the planner
+# would not pick by itself (small tiles -> everything multi-tile, other
+# workgroup sizes, forced pipelining, separate adapter kernels, 1 MiB slots).
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+K="not cli and not launch_configurations and not pipelined"
+for e in "QUACK_HIP_TILE=64" "QUACK_HIP_THREADS=512" "QUACK_HIP_TILE=128 QUACK_HIP_THREADS=256 QUACK_HIP_UNROLL=2" \
+         "QUACK_HIP_PIPE=2 QUACK_HIP_UNROLL=2" "QUACK_HIP_UNFUSED_ADAPTERS=1"; do
+  echo "== $e"
+  env $e timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -k "$K" 2>&1 | tail -2
+done
+echo "== QUACK_HIP_BATCH_MB=1"
+QUACK_HIP_BATCH_MB=1 timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -k "$K and not gapped and not promise" 2>&1 | tail -2
