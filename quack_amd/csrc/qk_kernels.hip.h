@@ -60,6 +60,13 @@ struct HistParams {
   const uint64_t *offsets;      // NULL => fixed-length batch; else start of every read (+ the end of the last
                                 //   one when `lengths` is NULL: packed batch, read r ends where r+1 starts)
   const uint32_t *lengths;      // gapped batch: length of every read (NULL: packed)
+  // Long ragged reads (several tiles): reads ordered by the number of tiles they
+  // reach, descending, so that the reads of tile t are order[0 .. reach[t]) and a
+  // far tile never looks at the reads that end before it (reach_* kernels below).
+  // NULL: natural order, every tile scans every read.
+  const uint32_t *order;
+  const uint32_t *reach;
+  uint32_t lengths_done;        // length_count / the kmers==NULL count were taken by ragged_length_kernel
   uint32_t *status;             // bit 0 is set when a batch submitted as 128-byte aligned is not
   uint32_t check_aligned;       // the batch was submitted as QK_BATCH_ALIGNED128 (whichever variant runs it)
   unsigned long long *table;    // planar [kOutRows][table_len]
@@ -376,18 +383,22 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     // the read and are parked beyond any read instead (they then never load)
     const int32_t cpos_s = (int32_t)P0 + 8 * ch_signed;
     const uint32_t cpos = cpos_s < 0 ? 0xFFFFFF00u : (uint32_t)cpos_s;
+    const bool sorted = !FIXED && p.order != nullptr;
+    const uint64_t list_len = sorted ? p.reach[tile] : p.n_reads;   // reads this tile has to look at
     const uint64_t r_begin = (uint64_t)slice * p.reads_per_slice;
     uint64_t r_end = r_begin + p.reads_per_slice;
-    if (r_end > p.n_reads) r_end = p.n_reads;
+    if (r_end > list_len) r_end = list_len;
     const uint32_t slice_reads = r_end > r_begin ? (uint32_t)(r_end - r_begin) : 0u;
     if (FIXED && tile == 0) fixed_reads += slice_reads;
     // 32-bit byte offsets relative to a 4-byte-aligned, workgroup-uniform base
     uint64_t slice_base = 0;
-    if (slice_reads) slice_base = FIXED ? r_begin * p.read_len : p.offsets[r_begin];
+    // (sorted: the slice's reads lie anywhere in the batch, which is < 4 GiB then: base 0)
+    if (slice_reads && !sorted) slice_base = FIXED ? r_begin * p.read_len : p.offsets[r_begin];
     const uint64_t base_al = slice_base & ~3ull;
     const uint8_t *qbase = p.qual + base_al;
     const uint8_t *sbase = p.seq + base_al;
-    const uint64_t *obase = FIXED ? nullptr : p.offsets + r_begin;
+    const uint64_t *obase = FIXED ? nullptr : p.offsets + (sorted ? 0 : r_begin);
+    const uint32_t *ord = sorted ? p.order + r_begin : nullptr;
     const uint64_t room = p.total_bytes - base_al;   // total_bytes >= base_al when slice_reads > 0
     const uint32_t off_limit = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
     const uint32_t cposp = cpos + (uint32_t)(slice_base & 3ull);
@@ -407,11 +418,15 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     // round trip and never spends a slot on a read that ends before the tile.
     // the offsets of the next pass are requested one pass ahead (each thread
     // stages the read `tid` of a pass), so staging never waits on memory
-    const uint32_t *lbase = (FIXED || !p.lengths) ? nullptr : p.lengths + r_begin;
+    const uint32_t *lbase = (FIXED || !p.lengths) ? nullptr : p.lengths + (sorted ? 0 : r_begin);
+    // read number `i` of the slice -> index into offsets[] / lengths[] (relative to obase / lbase)
+    auto read_id = [&](uint32_t i) { return ord ? ord[i] : i; };
     uint64_t pf0 = 0, pf1 = 0;
+    uint32_t pfid = 0;
     if (!FIXED && tid < slice_reads) {
-      pf0 = obase[tid];
-      pf1 = lbase ? pf0 + lbase[tid] : obase[tid + 1u];
+      pfid = read_id(tid);
+      pf0 = obase[pfid];
+      pf1 = lbase ? pf0 + lbase[pfid] : obase[pfid + 1u];
     }
     for (uint32_t pass = 0; pass < slice_reads; pass += FIXED ? slice_reads : kStageReads) {
       uint32_t n_list = slice_reads;   // FIXED: every read of the slice
@@ -423,18 +438,20 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         __syncthreads();
         for (uint32_t i = tid; i < (nb + 63u) / 64u * 64u; i += T) {   // whole waves: ballot below
           uint64_t o0 = 0;
-          uint32_t len = 0;
+          uint32_t len = 0, id = 0;
           if (i < nb) {
             if (T == kStageReads) {    // one read per thread: it was prefetched
               o0 = pf0;
               len = (uint32_t)(pf1 - pf0);
+              id = pfid;
             } else {
-              o0 = obase[pass + i];
-              len = lbase ? lbase[pass + i] : (uint32_t)(obase[pass + i + 1] - o0);
+              id = read_id(pass + i);
+              o0 = obase[id];
+              len = lbase ? lbase[id] : (uint32_t)(obase[id + 1] - o0);
             }
             if ((AL || p.check_aligned) && (o0 & 127u) != 0) atomicOr(p.status, 1u);   // the producer's promise does not hold
           }
-          if (tile == 0) {   // wave-uniform
+          if (tile == 0 && !p.lengths_done) {   // wave-uniform
             // length_count and the kmers==NULL count (quack.c:215-219), once per read.
             // Real batches are dominated by a few lengths (untrimmed reads), and
             // 64 lanes adding to one address serialise — for lengths past the
@@ -473,14 +490,16 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           if (reach) {
             const uint32_t slot_i = wave_base + (uint32_t)__builtin_popcountll(vote & ((1ull << lane_id) - 1ull));
             lds_list[slot_i] = make_uint2((uint32_t)(o0 - base_al), len);
-            if (ADAPT) lds_ridx[slot_i] = i;   // first_hit[] is indexed by the read, not by the list slot
+            // first_hit[] is indexed by the read, not by the list slot
+            if (ADAPT) lds_ridx[slot_i] = sorted ? id : (uint32_t)r_begin + id;
           }
         }
         __syncthreads();
         n_list = lds_misc[2];
         if (T == kStageReads && pass + kStageReads + tid < slice_reads) {
-          pf0 = obase[pass + kStageReads + tid];
-          pf1 = lbase ? pf0 + lbase[pass + kStageReads + tid] : obase[pass + kStageReads + tid + 1u];
+          pfid = read_id(pass + kStageReads + tid);
+          pf0 = obase[pfid];
+          pf1 = lbase ? pf0 + lbase[pfid] : obase[pfid + 1u];
         }
       }
 
@@ -512,12 +531,12 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           if (FIXED) {
             off = rel * p.read_len + cposp;
             len = p.read_len;
-            ridx[u] = rel;
+            ridx[u] = (uint32_t)r_begin + rel;
           } else {
             const uint2 e = PD > 1 ? lds_list[in_list ? rel : 0u] : de[u];
             off = e.x + cpos;
             len = e.y;
-            ridx[u] = ADAPT ? pass + (PD > 1 ? lds_ridx[in_list ? rel : 0u] : dr[u]) : 0u;
+            ridx[u] = ADAPT ? (PD > 1 ? lds_ridx[in_list ? rel : 0u] : dr[u]) : 0u;
           }
           // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
           // compute codes like their originals but count nothing
@@ -690,7 +709,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
                 }
               }
               if (best != kNoHit)
-                atomicMin(&p.first_hit[r_begin + ridx[u]], best);
+                atomicMin(&p.first_hit[ridx[u]], best);
             }
           }
         }
@@ -732,9 +751,10 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
 
   // ---- work loop
   uint32_t cur_tile = 0xFFFFFFFFu, reads_in_tile = 0;
+  auto tile_reads = [&](uint32_t tile) -> uint64_t { return (!FIXED && p.reach) ? p.reach[tile] : p.n_reads; };
   auto run_item = [&](uint32_t tile, uint32_t slice) {
-    const uint64_t rb = (uint64_t)slice * p.reads_per_slice;
-    const uint64_t re = rb + p.reads_per_slice < p.n_reads ? rb + p.reads_per_slice : p.n_reads;
+    const uint64_t rb = (uint64_t)slice * p.reads_per_slice, nt = tile_reads(tile);
+    const uint64_t re = rb + p.reads_per_slice < nt ? rb + p.reads_per_slice : nt;
     const uint32_t upcoming = re > rb ? (uint32_t)(re - rb) : 0u;
     if (tile != cur_tile || reads_in_tile + upcoming > kMaxReadsPerSlice) {
       if (cur_tile != 0xFFFFFFFFu) {
@@ -758,13 +778,31 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     // regions) and keep pulling slices of their tile; when it runs dry they
     // move on to the next tile that still has work, flushing only then.
     uint32_t tile = (uint32_t)(((uint64_t)blockIdx.x * p.n_tiles) / gridDim.x);
+    if (!FIXED && p.reach) {
+      // with the reads sorted by reach the work of a tile is known: home tiles in
+      // proportion to it (workgroup b starts where b's share of the read-tiles
+      // lies), so that few workgroups ever have to change tile and flush
+      if (tid == 0) {
+        uint64_t total = 0, acc = 0;
+        for (uint32_t t = 0; t < p.n_tiles; ++t) total += p.reach[t];
+        const uint64_t want = total * (2ull * blockIdx.x + 1ull) / (2ull * gridDim.x);
+        uint32_t t = 0;
+        for (; t + 1u < p.n_tiles; ++t) {
+          acc += p.reach[t];
+          if (acc > want) break;
+        }
+        lds_misc[1] = t;
+      }
+      __syncthreads();
+      tile = lds_misc[1];
+    }
     uint32_t dry = 0;
     while (dry < p.n_tiles) {
       __syncthreads();   // everybody has consumed lds_misc[1] of the previous round
       if (tid == 0) lds_misc[1] = atomicAdd(&p.queue[tile], 1u);
       __syncthreads();
       const uint32_t slice = lds_misc[1];
-      if (slice >= p.n_slices) {
+      if ((uint64_t)slice * p.reads_per_slice >= tile_reads(tile)) {
         tile = tile + 1u == p.n_tiles ? 0u : tile + 1u;
         ++dry;
         continue;
@@ -777,6 +815,112 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     if (keep == 0x12345678u) lds[0] = keep;
   }
   if (cur_tile != 0xFFFFFFFFu) flush(cur_tile);
+}
+
+// ---- pre-pass of long ragged batches: reads ordered by the tiles they reach --
+// bucket k = reads that reach exactly k tiles (k = ceil(len / tile_pos), capped);
+// order[] lists the reads by bucket, descending, so the reads that reach tile t
+// are order[0 .. reach[t]).  Counting sort: count -> scan -> scatter, both passes
+// over the reads privatised in LDS (one global atomic per bucket per block).
+constexpr int kReachThreads = 256;
+constexpr uint32_t kReachMaxTiles = 4096;
+
+__device__ __forceinline__ uint32_t tiles_reached(const HistParams &p, uint64_t r) {
+  const uint32_t len = p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]);
+  const uint32_t k = (len + p.tile_pos - 1u) / p.tile_pos;
+  return k < p.n_tiles ? k : p.n_tiles;
+}
+
+// counts[k] += reads of bucket k (counts: n_tiles + 1 words, zero on entry and
+// on exit); the block that finishes last turns them into
+//   reach[t]  = reads in buckets > t
+//   cursor[k] = first slot of bucket k in order[] (longest reads first)
+__global__ __launch_bounds__(kReachThreads) void reach_count_kernel(const HistParams p, uint32_t *counts, uint32_t *done,
+                                                                    uint32_t *reach, uint32_t *cursor) {
+  extern __shared__ uint32_t lc[];   // n_tiles + 1 counters, + 1 word for the ticket
+  const uint32_t nb = p.n_tiles + 1u;
+  for (uint32_t i = threadIdx.x; i < nb; i += kReachThreads) lc[i] = 0;
+  __syncthreads();
+  for (uint64_t r = (uint64_t)blockIdx.x * kReachThreads + threadIdx.x; r < p.n_reads; r += (uint64_t)gridDim.x * kReachThreads)
+    atomicAdd(&lc[tiles_reached(p, r)], 1u);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nb; i += kReachThreads)
+    if (lc[i]) atomicAdd(&counts[i], lc[i]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) lc[nb] = atomicAdd(done, 1u);
+  __syncthreads();
+  if (lc[nb] != gridDim.x - 1u) return;
+  // last block: every other block's counts are in (their atomics precede their ticket)
+  for (uint32_t i = threadIdx.x; i < nb; i += kReachThreads) lc[i] = atomicExch(&counts[i], 0u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *done = 0;
+    uint32_t above = 0;                      // reads in buckets > k
+    for (uint32_t k = p.n_tiles; k >= 1u; --k) {
+      const uint32_t c = lc[k];
+      lc[k] = above;                         // == cursor[k]: bucket k starts behind all longer reads
+      above += c;
+    }
+    lc[0] = above;                           // reads that reach at least one tile
+  }
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < p.n_tiles; t += kReachThreads) {
+    reach[t] = lc[t];                        // reads in buckets > t
+    cursor[t + 1u] = lc[t + 1u];
+  }
+}
+
+// order[]: block b owns a contiguous share of the reads; it counts its share per
+// bucket, reserves one range per bucket (one global atomic each), then places
+// its reads with LDS cursors.  (Same-address global atomics serialise at ~15 ns:
+// per-read or per-round reservations cost more than the whole rest of the pass.)
+__global__ __launch_bounds__(kReachThreads) void reach_scatter_kernel(const HistParams p, uint32_t *cursor, uint32_t *order) {
+  extern __shared__ uint32_t lc[];
+  const uint32_t nb = p.n_tiles + 1u;
+  const uint64_t share = (p.n_reads + gridDim.x - 1) / gridDim.x;
+  const uint64_t r0 = (uint64_t)blockIdx.x * share, r1 = r0 + share < p.n_reads ? r0 + share : p.n_reads;
+  for (uint32_t i = threadIdx.x; i < nb; i += kReachThreads) lc[i] = 0;
+  __syncthreads();
+  for (uint64_t r = r0 + threadIdx.x; r < r1; r += kReachThreads) atomicAdd(&lc[tiles_reached(p, r)], 1u);
+  __syncthreads();
+  for (uint32_t i = 1u + threadIdx.x; i < nb; i += kReachThreads)
+    if (lc[i]) lc[i] = atomicAdd(&cursor[i], lc[i]);   // count -> first slot of the block's range
+  __syncthreads();
+  for (uint64_t r = r0 + threadIdx.x; r < r1; r += kReachThreads) {
+    const uint32_t k = tiles_reached(p, r);
+    if (k) order[atomicAdd(&lc[k], 1u)] = (uint32_t)r;
+  }
+}
+
+// length_count and the kmers==NULL count (quack.c:215-219) of a ragged batch
+// that spans several tiles.  Inside hist_kernel only lengths below the tile
+// width have an LDS counter; longer ones would be one global atomic per read —
+// 5M reads of ~600 bases on 20 addresses: 11.3 ms instead of 1.3.  Here every
+// block privatises the first 8192 lengths in LDS (longer reads come in few
+// copies per length) and flushes what is non-zero.
+constexpr uint32_t kLenLds = 8192;
+__global__ __launch_bounds__(256) void ragged_length_kernel(const HistParams p) {
+  __shared__ uint32_t cnt[kLenLds];
+  __shared__ uint32_t gt10;
+  for (uint32_t i = threadIdx.x; i < kLenLds; i += 256) cnt[i] = 0;
+  if (threadIdx.x == 0) gt10 = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < p.n_reads; r += (uint64_t)gridDim.x * 256) {
+    const uint32_t len = p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]);
+    mine += len > 10u ? 1u : 0u;
+    if (len == 0) continue;
+    const uint32_t lp = len - 1u;
+    if (lp < kLenLds) atomicAdd(&cnt[lp], 1u);
+    else atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + lp], 1ull);
+  }
+  if (mine) atomicAdd(&gt10, mine);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kLenLds && i < p.table_len; i += 256)
+    if (cnt[i]) atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + i], (unsigned long long)cnt[i]);
+  if (threadIdx.x == 0 && p.no_adapters && gt10)
+    atomicAdd(&p.table[(uint64_t)kRowKmer * p.table_len + 10u], (unsigned long long)gt10);
 }
 
 // dst += src over the planar tables of two accumulators on the same device

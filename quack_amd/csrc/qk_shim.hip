@@ -97,6 +97,10 @@ struct qk_accum {
   // launches of one accumulator run in submission order even when they come
   // from different streams: they share the queue ring, the first-hit scratch
   // and the table's flush targets
+  // long ragged reads: reads ordered by the tiles they reach (qk::reach_* kernels)
+  uint32_t *d_order = nullptr;        // [order_cap]
+  uint64_t order_cap = 0;
+  uint32_t *d_reach = nullptr;        // [kReachMaxTiles] reach | [kReachMaxTiles + 1] counts | [kReachMaxTiles + 1] cursor
   uint32_t *d_status = nullptr;       // device word: bit 0 = an "aligned" batch was not aligned
   bool status_armed = false;
   hipEvent_t order_ev = nullptr;
@@ -166,7 +170,7 @@ struct Plan {
   int unroll, pipe;
   uint64_t reads_per_slice, n_slices, n_blocks;
   uint32_t bucket_log2, halo;
-  bool fused_adapters, dynamic, aligned;
+  bool fused_adapters, dynamic, aligned, sorted;
 };
 constexpr unsigned kQueueRing = 16;      // launches that may be in flight
 constexpr unsigned kQueueTiles = 8192;  // counters per launch
@@ -361,6 +365,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.check_aligned = (d_len && (flags & QK_BATCH_ALIGNED128)) ? 1u : 0u;
   if (hp.check_aligned) a->status_armed = true;
   hp.table = a->d_table;
+  hp.no_adapters = a->adapters ? 0 : 1;
   hp.first_hit = d_hit;
   hp.kmer_bits = a->d_kmer_bits;
   hp.kmer_filter = a->d_kmer_filter;
@@ -383,10 +388,50 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     hp.queue = a->d_queues + (size_t)(a->queue_seq++ % kQueueRing) * kQueueTiles;
     QK_HIP(hipMemsetAsync(hp.queue, 0, pl.n_tiles * sizeof(uint32_t), st));
   }
+  // several tiles, ragged: order the reads by the tiles they reach first, so that a
+  // far tile only looks at the reads that get there (config 5: most staging passes
+  // of the far tiles found next to nothing)
+  hp.order = nullptr;
+  hp.reach = nullptr;
+  hp.lengths_done = 0;
+  if (pl.dynamic && d_off != nullptr) {
+    // several tiles: lengths past the tile width have no LDS counter inside hist_kernel
+    const unsigned lb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 2048, (uint64_t)a->n_cu * 2));
+    hipLaunchKernelGGL(qk::ragged_length_kernel, dim3(lb), dim3(256), 0, st, hp);
+    QK_HIP(hipGetLastError());
+    hp.lengths_done = 1;
+  }
+  // (with two or three tiles nearly every read reaches every tile: nothing to gain)
+  pl.sorted = pl.dynamic && d_off != nullptr && total_bytes < 0xFFFFFF00ull && pl.n_tiles >= 4 &&
+              pl.n_tiles <= qk::kReachMaxTiles && !getenv("QUACK_HIP_NO_SORT");
+  if (pl.sorted) {
+    if (a->order_cap < n_reads) {
+      QK_HIP(hipDeviceSynchronize());
+      if (a->d_order) QK_HIP(hipFree(a->d_order));
+      a->d_order = nullptr;
+      a->order_cap = 0;
+      QK_HIP(hipMalloc((void **)&a->d_order, n_reads * sizeof(uint32_t)));
+      a->order_cap = n_reads;
+    }
+    const size_t reach_words = 3 * (size_t)qk::kReachMaxTiles + 4;   // reach | counts | cursor | done
+    if (!a->d_reach) {
+      QK_HIP(hipMalloc((void **)&a->d_reach, reach_words * sizeof(uint32_t)));
+      QK_HIP(hipMemsetAsync(a->d_reach, 0, reach_words * sizeof(uint32_t), st));   // counts and `done` stay zero between launches
+    }
+    uint32_t *reach = a->d_reach, *counts = reach + qk::kReachMaxTiles, *cursor = counts + qk::kReachMaxTiles + 1;
+    uint32_t *done = cursor + qk::kReachMaxTiles + 1;
+    const size_t lds = (pl.n_tiles + 2) * sizeof(uint32_t);
+    // few blocks: every block costs one same-address atomic per bucket (~15 ns each, serialised)
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 1024, (uint64_t)a->n_cu * 4));
+    hipLaunchKernelGGL(qk::reach_count_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, st, hp, counts, done, reach, cursor);
+    hipLaunchKernelGGL(qk::reach_scatter_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, st, hp, cursor, a->d_order);
+    QK_HIP(hipGetLastError());
+    hp.order = a->d_order;
+    hp.reach = reach;
+  }
   hp.row_dwords = qk::hist_row_dwords(pl.ch, pl.fused_adapters);
   hp.replicas = qk::hist_replicas(pl.ch, pl.fused_adapters);
   hp.halo = pl.halo;
-  hp.no_adapters = a->adapters ? 0 : 1;
 
   TimedLaunch tl{};
   if (a->timing) {
@@ -572,6 +617,8 @@ void qk_accum_destroy(qk_accum *a) {
   for (auto e : a->event_pool) (void)hipEventDestroy(e);
   if (a->d_queues) (void)hipFree(a->d_queues);
   if (a->d_status) (void)hipFree(a->d_status);
+  if (a->d_order) (void)hipFree(a->d_order);
+  if (a->d_reach) (void)hipFree(a->d_reach);
   if (a->d_hit_scratch) (void)hipFree(a->d_hit_scratch);
   if (a->d_kmer_bits) (void)hipFree(a->d_kmer_bits);
   if (a->d_kmer_filter) (void)hipFree(a->d_kmer_filter);

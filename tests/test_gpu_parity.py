@@ -87,6 +87,15 @@ def test_adapters_every_chunk_count_of_short_reads():
         assert_same(hip_table(seq, qual, off, kmers_bits=bits), ob.accumulate_batch(seq, qual, off, kmers=k))
 
 
+def test_many_reads_just_longer_than_a_tile():
+    """two or three tiles and few distinct lengths: length_count must not funnel
+    through a handful of global addresses (it took 11 ms per 3 Gbases), and the
+    unsorted multi-tile path still has users"""
+    for n, lo, hi in ((60000, 590, 600), (30000, 1100, 1101), (20000, 1, 2100)):
+        seq, qual, off = synth.ragged(n, lo, hi, seed=hi)
+        assert_same(hip_table(seq, qual, off), ob.accumulate_batch(seq, qual, off))
+
+
 def test_adapters_ragged_and_long():
     ads = synth.synthetic_adapters()
     k = ob.kmers_from_seqs(ads)
