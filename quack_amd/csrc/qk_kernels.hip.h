@@ -66,6 +66,7 @@ struct HistParams {
   // NULL: natural order, every tile scans every read.
   const uint32_t *order;
   const uint32_t *reach;
+  uint32_t stage_reads;         // ragged: reads staged per pass (a multiple of 1024: short reads want long passes)
   uint32_t lengths_done;        // length_count / the kmers==NULL count were taken by ragged_length_kernel
   uint32_t *status;             // bit 0 is set when a batch submitted as 128-byte aligned is not
   uint32_t check_aligned;       // the batch was submitted as QK_BATCH_ALIGNED128 (whichever variant runs it)
@@ -156,10 +157,12 @@ constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit window filter = 32 KiB o
 constexpr uint32_t kFusedFilter2Log2 = 17;  // second level, 16 KiB, keyed by the window's top 17 bits
 constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u + (1u << kFusedFilter2Log2) / 32u;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
-constexpr uint32_t kStageReads = 1024;      // ragged: read descriptors staged in LDS per pass
-inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false) {
+constexpr uint32_t kStageReads = 1024;      // ragged: read descriptors staged in LDS per pass (at least; HistParams::stage_reads)
+constexpr uint32_t kStageReadsMax = 8192;
+inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false,
+                             uint32_t stage_reads = kStageReads) {
   return ((size_t)kQRows * hist_row_dwords(ch, adapt) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords : 0u)) * sizeof(uint32_t) +
-         (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)kStageReads * (adapt ? 12 : 8) : 0);
+         (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)stage_reads * (adapt ? 12 : 8) : 0);
 }
 
 // Exact membership in the bucket table: km' = km*mul mod 2^20 (a bijection for
@@ -232,7 +235,8 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   // the reads of the current pass that reach this tile, compacted
   uint2 *lds_list = reinterpret_cast<uint2 *>(
       reinterpret_cast<char *>(lds_misc + 4u) + ((ADAPT && p.bucket_log2) ? (16u << p.bucket_log2) : 0u));
-  uint32_t *lds_ridx = reinterpret_cast<uint32_t *>(lds_list + kStageReads);   // ADAPT: index of a staged read within its pass
+  const uint32_t SR = FIXED ? kStageReads : p.stage_reads;
+  uint32_t *lds_ridx = reinterpret_cast<uint32_t *>(lds_list + SR);   // ADAPT: index of a staged read within its pass
   const uint64_t TL = p.table_len;
 
   if (ADAPT) {
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     const uint32_t win_mask = cpos >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cpos)) - 1u));
 
     // Fixed-length batches: one pass over the slice, read r at r*L.  Ragged
-    // batches: passes of kStageReads reads; each pass first stages, in LDS, the
+    // batches: passes of stage_reads reads; each pass first stages, in LDS, the
     // descriptors of the reads that reach this tile (coalesced offsets[] read,
     // wave-ballot compaction), so the loop below never waits on an offsets
     // round trip and never spends a slot on a read that ends before the tile.
@@ -428,10 +432,10 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
       pf0 = obase[pfid];
       pf1 = lbase ? pf0 + lbase[pfid] : obase[pfid + 1u];
     }
-    for (uint32_t pass = 0; pass < slice_reads; pass += FIXED ? slice_reads : kStageReads) {
+    for (uint32_t pass = 0; pass < slice_reads; pass += FIXED ? slice_reads : SR) {
       uint32_t n_list = slice_reads;   // FIXED: every read of the slice
       if (!FIXED) {
-        const uint32_t nb = slice_reads - pass < kStageReads ? slice_reads - pass : kStageReads;
+        const uint32_t nb = slice_reads - pass < SR ? slice_reads - pass : SR;
         static_assert(T == 1024 || T == 512 || T == 256, "staging assumes kStageReads is a multiple of T");
         __syncthreads();               // the previous pass has been consumed
         if (tid == 0) lds_misc[2] = 0;
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           uint64_t o0 = 0;
           uint32_t len = 0, id = 0;
           if (i < nb) {
-            if (T == kStageReads) {    // one read per thread: it was prefetched
+            if (T == SR) {    // one read per thread: it was prefetched
               o0 = pf0;
               len = (uint32_t)(pf1 - pf0);
               id = pfid;
@@ -496,8 +500,8 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         }
         __syncthreads();
         n_list = lds_misc[2];
-        if (T == kStageReads && pass + kStageReads + tid < slice_reads) {
-          pfid = read_id(pass + kStageReads + tid);
+        if (T == SR && pass + SR + tid < slice_reads) {
+          pfid = read_id(pass + SR + tid);
           pf0 = obase[pfid];
           pf1 = lbase ? pf0 + lbase[pfid] : obase[pfid + 1u];
         }
