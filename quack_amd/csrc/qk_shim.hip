@@ -173,8 +173,8 @@ struct Plan {
   uint32_t bucket_log2, halo;
   bool fused_adapters, dynamic, aligned, sorted;
 };
-constexpr unsigned kQueueRing = 16;      // launches that may be in flight
-constexpr unsigned kQueueTiles = 8192;  // counters per launch
+constexpr unsigned kQueueRing = 8;       // queue sets that rotate (launches of one accumulator run in order)
+constexpr unsigned kQueueTiles = 1u << 17;  // counters per launch: reads of up to 64 Mbases (512-position tiles)
 
 // Launch geometry.  One position tile whenever the LDS histogram of the whole
 // read fits (<= 576 positions, 448 with the adapter filter resident): tiles of
