@@ -96,6 +96,22 @@ def test_many_reads_just_longer_than_a_tile():
         assert_same(hip_table(seq, qual, off), ob.accumulate_batch(seq, qual, off))
 
 
+@pytest.mark.parametrize("n_adapters,length", [(400, 100), (6000, 200)])
+def test_large_adapter_sets_take_the_global_table(n_adapters, length):
+    """tens of thousands (up to most) of the 2^20 10-mers set: the exact LDS bucket
+    table no longer fits, filter hits are confirmed in the global bit set, and
+    nearly every window passes the filters"""
+    rng = np.random.default_rng(n_adapters)
+    ads = [bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, length)]) for _ in range(n_adapters)]
+    k = ob.kmers_from_seqs(ads)
+    bits = ob.kmers_to_bitset(k)
+    assert int(np.asarray(k).sum()) > 30000
+    seq, qual = synth.fixed(20000, 150, seed=7)
+    assert_same(hip_table(seq, qual, read_len=150, kmers_bits=bits), ob.accumulate_batch(seq, qual, read_len=150, kmers=k))
+    seq, qual, off = synth.ragged(400, 500, 6000, seed=8)
+    assert_same(hip_table(seq, qual, off, kmers_bits=bits), ob.accumulate_batch(seq, qual, off, kmers=k))
+
+
 def test_adapters_ragged_and_long():
     ads = synth.synthetic_adapters()
     k = ob.kmers_from_seqs(ads)
