@@ -20,7 +20,10 @@
  *     qual[total]   quality bytes, same offsets
  *     offsets[n+1]  u64 start offset of each read (offsets[n] == total);
  *                   NULL for a fixed-length batch (read r starts at r*read_len)
- * Algorithmic HBM traffic: 2 bytes per base (+ 8 bytes per read when ragged).
+ * (a third, gapped form — starts[n] + lengths[n], reads padded onto 128-byte
+ * cache lines — is described with qk_accum_submit_device_gapped below)
+ * Algorithmic HBM traffic: 2 bytes per base (+ 8 bytes per read when ragged,
+ * + 12 when gapped).
  *
  * Result layout: `qk_base_info`, bit-for-bit the reference's base_information
  * (97 x u64 = 776 bytes per position, quack.c:134-139).
