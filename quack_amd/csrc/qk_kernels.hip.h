@@ -847,6 +847,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
 // over the reads privatised in LDS (one global atomic per bucket per block).
 constexpr int kReachThreads = 256;
 constexpr uint32_t kReachMaxTiles = 4096;
+constexpr uint32_t kLenLds = 8192;   // lengths with an LDS counter in the length passes (see ragged_length_kernel)
 
 __device__ __forceinline__ uint32_t tiles_reached(const HistParams &p, uint64_t r) {
   const uint32_t len = p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]);
@@ -855,20 +856,39 @@ __device__ __forceinline__ uint32_t tiles_reached(const HistParams &p, uint64_t 
 }
 
 // counts[k] += reads of bucket k (counts: n_tiles + 1 words, zero on entry and
-// on exit); the block that finishes last turns them into
+// on exit), and the batch's length_count / kmers==NULL count while the lengths
+// are in hand; the block that finishes last turns the counts into
 //   reach[t]  = reads in buckets > t
 //   cursor[k] = first slot of bucket k in order[] (longest reads first)
 __global__ __launch_bounds__(kReachThreads) void reach_count_kernel(const HistParams p, uint32_t *counts, uint32_t *done,
                                                                     uint32_t *reach, uint32_t *cursor) {
   extern __shared__ uint32_t lc[];   // n_tiles + 1 counters, + 1 word for the ticket
+  __shared__ uint32_t len_cnt[kLenLds];   // ... and the batch's length_count on the way (ragged_length_kernel's job)
+  __shared__ uint32_t gt10;
   const uint32_t nb = p.n_tiles + 1u;
   for (uint32_t i = threadIdx.x; i < nb; i += kReachThreads) lc[i] = 0;
+  for (uint32_t i = threadIdx.x; i < kLenLds; i += kReachThreads) len_cnt[i] = 0;
+  if (threadIdx.x == 0) gt10 = 0;
   __syncthreads();
-  for (uint64_t r = (uint64_t)blockIdx.x * kReachThreads + threadIdx.x; r < p.n_reads; r += (uint64_t)gridDim.x * kReachThreads)
-    atomicAdd(&lc[tiles_reached(p, r)], 1u);
+  uint32_t mine = 0;
+  for (uint64_t r = (uint64_t)blockIdx.x * kReachThreads + threadIdx.x; r < p.n_reads; r += (uint64_t)gridDim.x * kReachThreads) {
+    const uint32_t len = p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]);
+    const uint32_t k = (len + p.tile_pos - 1u) / p.tile_pos;
+    atomicAdd(&lc[k < p.n_tiles ? k : p.n_tiles], 1u);
+    mine += len > 10u ? 1u : 0u;
+    if (len) {
+      if (len - 1u < kLenLds) atomicAdd(&len_cnt[len - 1u], 1u);
+      else atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + len - 1u], 1ull);
+    }
+  }
+  if (mine) atomicAdd(&gt10, mine);
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < nb; i += kReachThreads)
     if (lc[i]) atomicAdd(&counts[i], lc[i]);
+  for (uint32_t i = threadIdx.x; i < kLenLds && i < p.table_len; i += kReachThreads)
+    if (len_cnt[i]) atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + i], (unsigned long long)len_cnt[i]);
+  if (threadIdx.x == 0 && p.no_adapters && gt10)
+    atomicAdd(&p.table[(uint64_t)kRowKmer * p.table_len + 10u], (unsigned long long)gt10);
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) lc[nb] = atomicAdd(done, 1u);
@@ -922,7 +942,6 @@ __global__ __launch_bounds__(kReachThreads) void reach_scatter_kernel(const Hist
 // 5M reads of ~600 bases on 20 addresses: 11.3 ms instead of 1.3.  Here every
 // block privatises the first 8192 lengths in LDS (longer reads come in few
 // copies per length) and flushes what is non-zero.
-constexpr uint32_t kLenLds = 8192;
 __global__ __launch_bounds__(256) void ragged_length_kernel(const HistParams p) {
   __shared__ uint32_t cnt[kLenLds];
   __shared__ uint32_t gt10;

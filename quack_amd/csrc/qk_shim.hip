@@ -406,17 +406,19 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.order = nullptr;
   hp.reach = nullptr;
   hp.lengths_done = 0;
-  if (pl.dynamic && d_off != nullptr) {
+  // (with two or three tiles nearly every read reaches every tile: nothing to gain)
+  pl.sorted = pl.dynamic && d_off != nullptr && total_bytes < 0xFFFFFF00ull && pl.n_tiles >= 4 &&
+              pl.n_tiles <= qk::kReachMaxTiles && !getenv("QUACK_HIP_NO_SORT");
+  if (pl.dynamic && d_off != nullptr && !pl.sorted) {
     // several tiles: lengths past the tile width have no LDS counter inside hist_kernel
+    // (the sorted path takes them in its counting pass)
     const unsigned lb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 2048, (uint64_t)a->n_cu * 2));
     hipLaunchKernelGGL(qk::ragged_length_kernel, dim3(lb), dim3(256), 0, st, hp);
     QK_HIP(hipGetLastError());
     hp.lengths_done = 1;
   }
-  // (with two or three tiles nearly every read reaches every tile: nothing to gain)
-  pl.sorted = pl.dynamic && d_off != nullptr && total_bytes < 0xFFFFFF00ull && pl.n_tiles >= 4 &&
-              pl.n_tiles <= qk::kReachMaxTiles && !getenv("QUACK_HIP_NO_SORT");
   if (pl.sorted) {
+    hp.lengths_done = 1;
     if (a->order_cap < n_reads) {
       QK_HIP(hipDeviceSynchronize());
       if (a->d_order) QK_HIP(hipFree(a->d_order));
