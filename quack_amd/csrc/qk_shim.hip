@@ -316,7 +316,11 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
       checked = true;
     }
   }
-  QK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // The dynamic-LDS ceiling is a property of the function, shared by every thread and
+  // accumulator of the process: always the full 160 KiB, never "what this launch needs"
+  // (the two mates of a pair are accumulated by two host threads, and reads of different
+  // lengths would otherwise lower each other's ceiling between attribute and launch).
+  QK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL(k, grid, dim3(T), lds, st, hp);
   QK_HIP(hipGetLastError());
   return QK_OK;

@@ -311,6 +311,38 @@ def test_a_false_alignment_promise_is_detected():
         hip_gapped(gs, gq, starts, lens, True, None, device=False)      # found by the host check at commit
 
 
+def test_two_host_threads_with_different_geometries():
+    """the two mates of a pair are accumulated by two host threads (cli.c); their reads
+    may differ in length, i.e. in kernel variant and LDS size — per-function state of
+    the runtime (the dynamic-LDS ceiling) must not depend on who launched last"""
+    import threading
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    jobs = [dict(L=300, n=3000, bits=ob.kmers_to_bitset(k), k=k), dict(L=36, n=20000, bits=None, k=None),
+            dict(L=150, n=6000, bits=None, k=None), dict(L=72, n=9000, bits=ob.kmers_to_bitset(k), k=k)]
+    out, err = {}, []
+
+    def work(i, j):
+        try:
+            with quack_amd.Accumulator(0, j["bits"]) as acc:
+                for rep in range(25):
+                    seq, qual = synth.fixed(j["n"], j["L"], seed=100 * i + rep)
+                    acc.submit_fixed(seq, qual, j["L"])
+                sd = acc.finish()
+            out[i] = (sd.bases, sd.number_of_sequences)
+        except Exception as e:            # noqa: BLE001 - reported below
+            err.append((i, e))
+
+    th = [threading.Thread(target=work, args=(i, j)) for i, j in enumerate(jobs)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not err, err
+    for i, j in enumerate(jobs):
+        seq = np.concatenate([synth.fixed(j["n"], j["L"], seed=100 * i + rep)[0] for rep in range(25)])
+        qual = np.concatenate([synth.fixed(j["n"], j["L"], seed=100 * i + rep)[1] for rep in range(25)])
+        assert_same(out[i], ob.accumulate_batch(seq, qual, read_len=j["L"], kmers=j["k"]))
+
+
 def test_submits_from_several_streams_into_one_accumulator():
     """device-resident batches enqueued from three streams, un-synchronised, with
     pinned-slot batches in between: launches of one accumulator share its work
