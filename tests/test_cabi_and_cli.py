@@ -51,7 +51,7 @@ def test_no_device_is_a_loud_error_not_a_fallback():
         quack_amd.Accumulator(0)
     with pytest.raises(quack_amd.HipUnavailable):
         quack_amd.read_fastq(cases.inp("kat.fq"))
-    r = subprocess.run([QUACK, "-u", cases.inp("kat.fq")], capture_output=True)
+    r = subprocess.run([QUACK, "-u", cases.inp("kat.fq")], capture_output=True, timeout=240)
     assert r.returncode == 1 and r.stdout == b"" and b"no HIP device" in r.stderr
 
 
@@ -70,12 +70,12 @@ def test_product_does_not_reference_the_oracle():
 @pytest.mark.parametrize("name,argv", cases.load("cli_cases.tsv"), ids=[c[0] for c in cases.load("cli_cases.tsv")])
 def test_cli_without_inputs(name, argv):
     g = os.path.join(cases.G, "cli", name)
-    r = subprocess.run([QUACK] + argv, capture_output=True, cwd=cases.inp(""))
+    r = subprocess.run([QUACK] + argv, capture_output=True, cwd=cases.inp(""), timeout=240)
     assert r.stdout == open(g + ".out", "rb").read()
     assert r.stderr == open(g + ".err", "rb").read()
     assert r.returncode == int(open(g + ".rc").read())
 
 
 def test_missing_input_gives_no_partial_svg():
-    r = subprocess.run([QUACK, "-u", "/nonexistent/reads.fq.gz"], capture_output=True)
+    r = subprocess.run([QUACK, "-u", "/nonexistent/reads.fq.gz"], capture_output=True, timeout=240)
     assert r.returncode != 0 and r.stdout == b"" and r.stderr != b""

@@ -477,7 +477,7 @@ QUACK = os.path.join(cases.ROOT, "quack_amd", "host", "quack")
 @pytest.mark.parametrize("name,argv", cases.load(), ids=[c[0] for c in cases.load()])
 def test_cli_is_a_drop_in(name, argv):
     """the C CLI on the GPU writes the reference binary's bytes"""
-    r = subprocess.run([QUACK] + argv, capture_output=True, cwd=cases.inp(""))
+    r = subprocess.run([QUACK] + argv, capture_output=True, cwd=cases.inp(""), timeout=240)
     assert r.returncode == 0, r.stderr
     assert r.stderr == cases.golden_err(name)
     assert r.stdout == cases.golden_svg(name)
@@ -563,7 +563,7 @@ def test_cli_sharded_over_three_accumulators(name):
     """QUACK_DEVICES=0,0,0: the CLI's multi-device path on one GPU"""
     argv = dict(cases.load())[name]
     r = subprocess.run([QUACK] + argv, capture_output=True, cwd=cases.inp(""),
-                       env=dict(os.environ, QUACK_DEVICES="0,0,0", QUACK_HIP_BATCH_MB="1"))
+                       env=dict(os.environ, QUACK_DEVICES="0,0,0", QUACK_HIP_BATCH_MB="1"), timeout=240)
     assert r.returncode == 0, r.stderr
     assert r.stdout == cases.golden_svg(name)
 
