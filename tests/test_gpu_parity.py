@@ -333,9 +333,11 @@ def test_two_host_threads_with_different_geometries():
         except Exception as e:            # noqa: BLE001 - reported below
             err.append((i, e))
 
-    th = [threading.Thread(target=work, args=(i, j)) for i, j in enumerate(jobs)]
-    [t.start() for t in th]
-    [t.join() for t in th]
+    for pair in ((0, 1), (2, 3)):       # two at a time, like the CLI's forward / reverse threads
+        th = [threading.Thread(target=work, args=(i, jobs[i])) for i in pair]
+        [t.start() for t in th]
+        [t.join(timeout=150) for t in th]
+        assert not any(t.is_alive() for t in th), "a host thread is stuck"
     assert not err, err
     for i, j in enumerate(jobs):
         seq = np.concatenate([synth.fixed(j["n"], j["L"], seed=100 * i + rep)[0] for rep in range(25)])
