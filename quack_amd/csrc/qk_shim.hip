@@ -16,7 +16,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "qk_adapter_kernels.hip.h"
@@ -320,7 +323,19 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
   // accumulator of the process: always the full 160 KiB, never "what this launch needs"
   // (the two mates of a pair are accumulated by two host threads, and reads of different
   // lengths would otherwise lower each other's ceiling between attribute and launch).
-  QK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // ... and once per function and device, under a lock: the runtime call rewrites function
+  // metadata that a concurrent launch of the same function reads.
+  {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    QK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done.count({(const void *)k, dev})) {
+      QK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      done.insert({(const void *)k, dev});
+    }
+  }
   hipLaunchKernelGGL(k, grid, dim3(T), lds, st, hp);
   QK_HIP(hipGetLastError());
   return QK_OK;
