@@ -286,7 +286,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   // go one step further: the tail masks are per-lane constants (fm0/fm1), lanes past
   // the end of the slice sit out under the exec mask and count their own
   // events (steps_v), and no per-event valid counter is needed at all.
-  constexpr bool FAST_FIXED = FIXED && !ADAPT;
+  constexpr bool FAST_FIXED = FIXED;
   uint32_t events = 0, steps_v = 0, fm0 = 0xFFFFFFFFu, fm1 = 0xFFFFFFFFu;
 
   auto spill = [&]() {
@@ -332,6 +332,8 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
       n_gt10 = 0;
     }
     __syncthreads();
+    // fixed-length batches count unmasked: columns at and behind read_len hold the next read's bytes
+    const uint32_t pos_limit = (FIXED && p.read_len < p.table_len) ? p.read_len : p.table_len;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     for (uint32_t row = 33u + wave; row <= 123u; row += T / 64) {  // quack.c:203: bin = byte - 33
       for (uint32_t pp = lane; pp < TP; pp += 64u) {
@@ -342,14 +344,14 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           c += (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
         }
         const uint32_t pos = P0 + pp;
-        if (c != 0 && pos < p.table_len)
+        if (c != 0 && pos < pos_limit)
           atomicAdd(&p.table[(uint64_t)(row - 33u) * TL + pos], (unsigned long long)c);
       }
     }
     for (uint32_t pp = tid; pp < TP; pp += T) {
       const uint32_t v = lds_base[pp];
       const uint32_t pos = P0 + pp;
-      if (v == 0 || pos >= p.table_len) continue;
+      if (v == 0 || pos >= pos_limit) continue;
       const uint32_t t = lds_base[TP + pp], c = lds_base[2u * TP + pp], g = lds_base[3u * TP + pp];
       unsigned long long *row0 = &p.table[(uint64_t)kRowContent * TL + pos];
       const uint32_t a = v - t - c - g;                     // content[] order: A,T,C,G (quack.c:150)
@@ -582,15 +584,17 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         // reads): the whole wave moves on.  ADAPT needs every lane's codes, but
         // then no lane has a valid window either.
         if (!FIXED && __builtin_amdgcn_ballot_w64(n != 0) == 0) continue;
-        if (FAST_FIXED && n == 0) continue;   // per lane: past the end of the slice (its last step only)
+        if (FAST_FIXED && !ADAPT && n == 0) continue;   // per lane: past the end of the slice (its last step only)
         const uint2 qa = window8(q[u], sk[u]);
         const uint2 sa = window8(s[u], sk[u]);
-        // tail masks: per-lane constants in a fixed-length batch (n is then
-        // the lane's constant or, past the end of the slice, zero)
-        const uint32_t m0 = FAST_FIXED ? fm0 : FIXED ? (n ? fm0 : 0xFFFFFFFFu)
-                                             : (n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n)));
-        const uint32_t m1 = FAST_FIXED ? fm1 : FIXED ? (n ? fm1 : 0xFFFFFFFFu)
-                                             : (n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (n - 4u)))));
+        // Ragged: bytes past the end of the read -> 0xFF (quality row 127 is
+        // discarded at flush time, 0xFF & 31 matches none of T/C/G).  Fixed
+        // length: no masks at all — the bytes behind a read's last base belong
+        // to the next read and count into columns >= read_len, which the flush
+        // never looks at; lanes with nothing to count (past the end of the
+        // slice, feeder and halo lanes) sit the counting out under the exec mask.
+        const uint32_t m0 = FAST_FIXED ? 0u : (n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n)));
+        const uint32_t m1 = FAST_FIXED ? 0u : (n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (n - 4u)))));
         const uint32_t mk[2] = {m0, m1};
         const uint32_t qw[2] = {qa.x | m0, qa.y | m1};
         const uint32_t sw[2] = {sa.x | m0, sa.y | m1};
@@ -598,7 +602,8 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           keep ^= qw[0] ^ qw[1] ^ sw[0] ^ sw[1];
           continue;
         }
-        if (MODE == 0 || MODE == 2) {
+        const bool count_me = !FAST_FIXED || n != 0;   // ragged: every lane (masked bytes take care of themselves)
+        if ((MODE == 0 || MODE == 2) && count_me) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const uint32_t b = __builtin_amdgcn_ubfe(qw[j >> 2], 8 * (j & 3), 7);
@@ -606,36 +611,35 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           }
         }
         if (MODE == 0 || MODE == 3) {
-          // letter indicators come from the UNMASKED bytes when the adapter scan
-          // needs them (feeder lanes and chunk tails must still yield the real
-          // codes; window validity is enforced by `hits` masks below) and are
-          // masked per byte for the content counters
-          uint32_t b0[2], b1[2];
+          // letter indicators: the adapter scan needs those of the real bytes
+          // (feeder lanes and chunk tails must still yield the real codes; window
+          // validity is enforced by the `hits` masks below); the counters of a
+          // ragged batch need every masked byte to read "not equal"
+          uint32_t b0[2] = {0, 0}, b1[2] = {0, 0}, nt[2], nc[2], ng[2];
           const uint32_t raw[2] = {sa.x, sa.y};
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
-            if (!ADAPT) {
-              acc_t[d] += swar_ne(sw[d], kKeyT);
-              acc_c[d] += swar_ne(sw[d], kKeyC);
-              acc_g[d] += swar_ne(sw[d], kKeyG);
-              if (!FAST_FIXED) acc_v[d] += mk[d] & 0x01010101u;   // invalid events
-              b0[d] = b1[d] = 0;
-            } else {
-              // the scan needs the indicators of the real bytes; the counters
-              // need every masked byte to read "not equal"
-              const uint32_t inv01 = mk[d] & 0x01010101u;
-              const uint32_t nt = swar_ne(raw[d], kKeyT), nc = swar_ne(raw[d], kKeyC), ng = swar_ne(raw[d], kKeyG);
-              acc_t[d] += nt | inv01;
-              acc_c[d] += nc | inv01;
-              acc_g[d] += ng | inv01;
-              acc_v[d] += inv01;
-              // code bits: low = T or G, high = C or G (at most one letter matches)
-              b0[d] = (nt & ng) ^ 0x01010101u;
-              b1[d] = (nc & ng) ^ 0x01010101u;
+            const uint32_t src = ADAPT ? raw[d] : sw[d];
+            nt[d] = swar_ne(src, kKeyT);
+            nc[d] = swar_ne(src, kKeyC);
+            ng[d] = swar_ne(src, kKeyG);
+            if (ADAPT) {   // code bits: low = T or G, high = C or G (at most one letter matches)
+              b0[d] = (nt[d] & ng[d]) ^ 0x01010101u;
+              b1[d] = (nc[d] & ng[d]) ^ 0x01010101u;
             }
           }
-          if (FAST_FIXED) steps_v += 1u;
-          else events += 1u;
+          if (count_me) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const uint32_t inv01 = (ADAPT && !FAST_FIXED) ? (mk[d] & 0x01010101u) : 0u;
+              acc_t[d] += nt[d] | inv01;
+              acc_c[d] += nc[d] | inv01;
+              acc_g[d] += ng[d] | inv01;
+              if (!FAST_FIXED) acc_v[d] += mk[d] & 0x01010101u;   // events in which the byte was masked
+            }
+            if (FAST_FIXED) steps_v += 1u;
+          }
+          if (!FAST_FIXED) events += 1u;
           if (ADAPT) {
             // 2-bit codes A0 T1 C2 G3 (quack.c:150) of the 8 owned bases, first
             // base most significant: byte codes -> 8 bits per dword by multiply
