@@ -39,6 +39,10 @@
 #include "inflate_fast.h"
 
 enum { WIN = 32768, MAX_THREADS = 32 };
+/* memory bounds: a slice that inflates past SPEC_MAX bytes is not worth speculating on (FASTQ is 4-5x;
+ * this is 32x) and is decoded in order instead; buffers that grew past KEEP_MAX are given back after use */
+#define SPEC_MAX ((size_t)32 << 20)
+#define KEEP_MAX ((size_t)64 << 20)
 
 typedef struct {
   uint16_t *b16;   /* WIN markers + speculative output */
@@ -120,6 +124,7 @@ static void speculate(qkh_pinflate *p, unsigned k, pslot *s, qkh_inflate *z, spe
     if (n == s->cap16 && grow16(s, n + 1)) return;
     long got = qkh_inflate_read16(z, s->b16 + WIN + n, s->cap16 - n, WIN + n);
     if (got > 0) n += (size_t)got;
+    if (n > SPEC_MAX) return;              /* see SPEC_MAX */
     if (z->state == QKH_Z_ERROR) return;   /* garbage, or a damaged file: decided in order */
     if (z->stopped || z->state == QKH_Z_DONE) break;
     if (got <= 0) return;
@@ -317,6 +322,14 @@ int qkh_pinflate_next(qkh_pinflate *p, const uint8_t **data, size_t *len) {
     pslot *s;
     pthread_mutex_lock(&p->mu);
     if (p->holding) {
+      pslot *h = &p->slots[p->tail % p->n_slots];
+      if (h->cap8 > KEEP_MAX || h->cap16 > KEEP_MAX) {   /* an unusually compressible slice: do not keep its buffers */
+        free(h->b8);
+        free(h->b16);
+        h->b8 = NULL;
+        h->b16 = NULL;
+        h->cap8 = h->cap16 = 0;
+      }
       p->holding = 0;
       p->tail++;
       pthread_cond_broadcast(&p->cv);
