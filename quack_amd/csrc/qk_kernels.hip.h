@@ -593,8 +593,13 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         // to the next read and count into columns >= read_len, which the flush
         // never looks at; lanes with nothing to count (past the end of the
         // slice, feeder and halo lanes) sit the counting out under the exec mask.
-        const uint32_t m0 = FAST_FIXED ? 0u : (n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n)));
-        const uint32_t m1 = FAST_FIXED ? 0u : (n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (n - 4u)))));
+        // (a ragged wave whose lanes all hold 8 valid bytes — the inside of long
+        // reads — skips the mask arithmetic: a wave-uniform branch)
+        uint32_t m0 = 0u, m1 = 0u;
+        if (!FAST_FIXED && __builtin_amdgcn_ballot_w64(n != 8u) != 0) {
+          m0 = n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n));
+          m1 = n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (n - 4u))));
+        }
         const uint32_t mk[2] = {m0, m1};
         const uint32_t qw[2] = {qa.x | m0, qa.y | m1};
         const uint32_t sw[2] = {sa.x | m0, sa.y | m1};
