@@ -400,6 +400,14 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
     uint64_t slice_base = 0;
     // (sorted: the slice's reads lie anywhere in the batch, which is < 4 GiB then: base 0)
     if (slice_reads && !sorted) slice_base = FIXED ? r_begin * p.read_len : p.offsets[r_begin];
+    if (!FIXED) {
+      // offsets[] comes through a vector load: tell the compiler the value is the
+      // same in every lane, or the two base pointers below live in VGPRs and
+      // every load of the loop pays two v_readfirstlane + s_nop for them
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)slice_base);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(slice_base >> 32));
+      slice_base = ((uint64_t)hi << 32) | lo;
+    }
     const uint64_t base_al = slice_base & ~3ull;
     const uint8_t *qbase = p.qual + base_al;
     const uint8_t *sbase = p.seq + base_al;
