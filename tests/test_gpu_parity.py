@@ -577,8 +577,11 @@ def test_device_table_roundtrip_and_single_rank_allreduce():
     from quack_amd import distributed as qd
     seq, qual, off = synth.ragged(20000, 1, 150, seed=51)
     want = ob.accumulate_batch(seq, qual, off)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    import socket
+    with socket.socket() as sk:               # a free port, not a fixed one
+        sk.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         with quack_amd.Accumulator(0) as acc:
