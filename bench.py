@@ -2,65 +2,134 @@
 """bench.py — headline benchmark of the accumulation path (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N>1 without a launcher (WORLD_SIZE unset): this process starts N fresh child
+ranks itself — before it imports torch or touches the GPU — relays rank 0's
+JSON line and exits non-zero if any rank does.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
+ranks come from the launcher (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
 
 A "step" is one pass of the hot path (histogram kernel[s]) over one batch of
-synthetic reads that is already resident in HBM.  Workload at N=1 = the
-configuration the metric is quoted on: 10M-read synthetic 150 bp FASTQ, no
-adapters (BASELINE.json configs[1]); every rank holds its own 10M-read batch
-(weak scaling; the path shards by read batch with no data-path collective),
-and the job ends with the single RCCL all-reduce of the integer tables, which
-is inside the timed region.
+synthetic reads that is already resident in HBM.
+
+  N = 1   the configuration the metric is quoted on: 10M-read synthetic 150 bp
+          FASTQ, no adapters (BASELINE.json configs[1]); afterwards, outside
+          the headline's timed region, the same run times configs[2] (10M x
+          300 bp + adapters, 25 % of the reads carrying a spliced adapter) and
+          configs[4] (ragged 1-20 kb) for a few steps each -> "also".
+  N > 1   configs[3]'s per-GPU share: paired 2 x 50M x 150 bp over 8 GPUs =
+          2 x 6.25M reads per GPU, two independent accumulators (forward /
+          reverse mate, quack.c:911-921); weak scaling — every rank holds its
+          own share, there is no data-path collective, and the job ends with
+          ONE RCCL all-reduce of each mate's integer table, inside the timed
+          region.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     dominant kernel, algorithmic bytes (2 B/base [+8 B/read ragged])
-               / average launch duration from HIP events on the launch stream
+  roofline     dominant kernel, algorithmic bytes (2 B/base [+8 B/read ragged,
+               +12 gapped]) / average launch duration from HIP events on the
+               launch stream; `batch_ms` = all kernels of a step
   cpu_baseline the oracle (CPU restatement, kind "port") on one host core over
-               the same batch — a reported baseline, not the target
+               the same bytes; cpu_baseline_threads = the same on every host
+               core the process may use — reported baselines, not the target
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-import quack_amd  # noqa: E402  (fails loudly when the native libraries are missing)
-from quack_amd import distributed as qd  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+METRIC = "bases/sec on synthetic 150 bp FASTQ; achieved HBM GB/s vs peak"
+TRAFFIC_SOURCE = "profiles/hbm_traffic.json (rocprofv3 --pmc passes, builder-run; not measured in this run)"
 
 WORKLOADS = {
     # name: (reads, read_len, ragged (lo, hi), adapters, BASELINE.json config)
     "cfg2": dict(n=10_000_000, L=150, ragged=None, adapters=False,
                  label="10M-read synthetic 150 bp FASTQ, no adapters (BASELINE.json configs[1])"),
-    "cfg3": dict(n=10_000_000, L=300, ragged=None, adapters=True,
-                 label="10M-read synthetic 300 bp FASTQ + adapter FASTA (configs[2])"),
+    "cfg3": dict(n=10_000_000, L=300, ragged=None, adapters=True, splice=0.25,
+                 label="10M-read synthetic 300 bp FASTQ + adapter FASTA, 25% of reads with a spliced adapter (configs[2])"),
     # long reads live in HBM the way the host feed lays them out (pipeline.c): every read starts on a
     # 128-byte cache line (QK_BATCH_ALIGNED128); cfg5packed = the same reads without the padding
     "cfg5": dict(n=143_000, L=20000, ragged=(1000, 20000), adapters=False, aligned=True,
                  label="PacBio-style ragged 1-20 kb synthetic FASTQ, reads on 128-B lines as the host feed lays them out (configs[4])"),
     "cfg5packed": dict(n=143_000, L=20000, ragged=(1000, 20000), adapters=False,
-                 label="PacBio-style ragged 1-20 kb synthetic FASTQ, packed (configs[4])"),
+                       label="PacBio-style ragged 1-20 kb synthetic FASTQ, packed (configs[4])"),
     # configs[3]: paired 2 x 50M x 150 bp over 8 GPUs -> per GPU 2 x 6.25M reads; the two mates are two
     # independent accumulations (quack.c:911-921); R2 qualities skewed lower (SURVEY 8d)
     "cfg4": dict(n=6_250_000, L=150, ragged=None, adapters=False, paired=True,
                  label="paired 2x50M 150 bp sharded over 8 GPUs: per-GPU share 2 x 6.25M reads (configs[3])"),
+    # trimmed Illumina: 150 bp reads, most of them full length, the rest cut back to 120..149
+    "trimmed": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7,
+                    label="10M-read synthetic trimmed 150 bp FASTQ (70% full length, rest 120-149), ragged"),
 }
 
 
-def make_batch(w, seed, device, quality="uniform", q_hi_override=None):
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS),
+                    help="auto: cfg2 at N=1 (the headline), cfg4's per-GPU share at N>1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="N=1: skip the cfg3 / cfg5 lines")
+    ap.add_argument("--also-steps", type=int, default=20)
+    # rehearsal on a one-GPU box: several ranks share one device and the table
+    # exchange goes through gloo (the driver's runs use the defaults: nccl = RCCL)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--device", type=int, default=None, help="force this device for every rank")
+    ap.add_argument("--reads", type=int, default=None, help="override reads per GPU (rehearsals)")
+    ap.add_argument("--quality", default="uniform", choices=["uniform", "novaseq4"],
+                    help="novaseq4: Q in {2,12,23,37} with 3/5/12/80 %% (stress for same-bin LDS atomics)")
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------
+# N>1 without a launcher: start the ranks ourselves.  Runs BEFORE torch /
+# quack_amd are imported: the parent never initialises HIP, every rank is a
+# fresh child process (never an exec of a process that touched the GPU).
+def self_launch(args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 writes the JSON line to our stdout; the other ranks have nothing to say there
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                for o in pending:          # a rank died: the others would wait in the collective for ever
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# --------------------------------------------------------------------------
+def make_batch(torch, np, w, seed, device, quality="uniform", q_hi_override=None, ads=None):
     g = torch.Generator(device=device).manual_seed(seed)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
     if w["ragged"]:
         rng = np.random.default_rng(seed)
         lens = rng.integers(w["ragged"][0], w["ragged"][1] + 1, w["n"])
+        if w.get("full"):
+            lens[rng.random(w["n"]) < w["full"]] = w["ragged"][1]
         d_len = None
         if w.get("aligned"):
             starts = np.concatenate([[0], np.cumsum((lens + 127) // 128 * 128)]).astype(np.int64)
@@ -72,7 +141,7 @@ def make_batch(w, seed, device, quality="uniform", q_hi_override=None):
             extent = int(off[-1])
             d_off = torch.from_numpy(off).to(device)
         total, max_len = int(lens.sum()), int(lens.max())
-        q_lo, q_hi = 1, 60
+        q_lo, q_hi = (1, 60) if w["L"] > 1000 else (2, 41)
     else:
         total, max_len, d_off, d_len = w["n"] * w["L"], w["L"], None, None
         extent = total
@@ -90,13 +159,30 @@ def make_batch(w, seed, device, quality="uniform", q_hi_override=None):
             qual[a:b] = levels[idx]
         else:
             qual[a:b] = (33 + torch.randint(q_lo, q_hi + 1, (b - a,), generator=g, device=device)).to(torch.uint8)
-    return seq, qual, d_off, total, max_len, d_len, extent
+    spliced = 0
+    if ads is not None and w.get("splice") and d_off is None:
+        # a quarter of the reads get one adapter at a uniform offset, truncated at the
+        # read end — first-hit, hit-at-the-end and no-hit paths are all in the timed region
+        L, n = w["L"], w["n"]
+        pick = torch.nonzero(torch.rand(n, generator=g, device=device) < w["splice"]).flatten()
+        which = torch.randint(0, len(ads), (len(pick),), generator=g, device=device)
+        at = torch.randint(0, L, (len(pick),), generator=g, device=device)
+        width = max(len(a) for a in ads)
+        tab = torch.zeros((len(ads), width), dtype=torch.uint8, device=device)
+        alen = torch.tensor([len(a) for a in ads], device=device)
+        for i, a in enumerate(ads):
+            tab[i, :len(a)] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        for j in range(width):
+            ok = (at + j < L) & (j < alen[which])
+            seq[(pick * L + at + j)[ok]] = tab[which[ok], j]
+        spliced = int(len(pick))
+    return dict(seq=seq, qual=qual, d_off=d_off, d_len=d_len, total=total, max_len=max_len, extent=extent,
+                n=w["n"], spliced=spliced)
 
 
-def synthetic_adapter_bits(seed=3):
+def synthetic_adapter_bits(np, seed=3):
     """config 3's adapter FASTA: 24 records of 30-60 nt -> 2^20-bit table via
     the product's read_adapters rule (quack_amd.host qkh_adapter_insert)"""
-    import ctypes
     from quack_amd import _capi
     rng = np.random.default_rng(seed)
     bits = np.zeros(_capi.QK_KMER_TABLE_WORDS, dtype=np.uint32)
@@ -109,63 +195,143 @@ def synthetic_adapter_bits(seed=3):
     return bits, ads
 
 
-def cpu_baseline(seq, qual, d_off, n, total, w, ads, d_len=None):
-    """oracle on one host core over (a bounded sample of) the same batch"""
+def alg_bytes_of(b):
+    return 2.0 * b["total"] + ((12.0 if b["d_len"] is not None else 8.0) * b["n"] if b["d_off"] is not None else 0.0)
+
+
+def host_sample(np, b, w, budget_bases):
+    """the first reads of the GPU batch, packed, on the host: (seq, qual, offsets or None, reads, bases)"""
+    n = b["n"]
+    if b["d_off"] is None:
+        m = min(n, max(1, budget_bases // w["L"]))
+        return b["seq"][:m * w["L"]].cpu().numpy(), b["qual"][:m * w["L"]].cpu().numpy(), None, m, m * w["L"]
+    if b["d_len"] is not None:   # gapped on the device: the oracle takes the same reads packed
+        starts, lens = b["d_off"].cpu().numpy().astype(np.int64), b["d_len"].cpu().numpy().astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        m = int(min(n, max(1, np.searchsorted(off, budget_bases))))
+        end = int(starts[m - 1] + lens[m - 1])
+        gs, gq = b["seq"][:end].cpu().numpy(), b["qual"][:end].cpu().numpy()
+        keep = np.zeros(end, dtype=bool)
+        for a, l in zip(starts[:m], lens[:m]):
+            keep[a:a + l] = True
+        return gs[keep], gq[keep], off[:m + 1], m, int(off[m])
+    off = b["d_off"].cpu().numpy().astype(np.uint64)
+    m = int(min(n, max(1, np.searchsorted(off, budget_bases))))
+    return b["seq"][:int(off[m])].cpu().numpy(), b["qual"][:int(off[m])].cpu().numpy(), off[:m + 1], m, int(off[m])
+
+
+def cpu_baselines(np, b, w, ads, threads=True, budget=3_000_000_000):
+    """the oracle over (a bounded sample of) the same bytes: one core, then every core we may use"""
+    import threading
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
-    budget_bases = 3_000_000_000     # ~12 s at ~0.25 Gbases/s
     kmers = ob.kmers_from_seqs([bytes(a) for a in ads]) if ads is not None else None
-    if d_off is None:
-        m = min(n, max(1, budget_bases // w["L"]))
-        hs, hq = seq[:m * w["L"]].cpu().numpy(), qual[:m * w["L"]].cpu().numpy()
-        t0 = time.perf_counter()
-        ob.accumulate_batch(hs, hq, read_len=w["L"], kmers=kmers)
-        dt = time.perf_counter() - t0
-        bases, sample = m * w["L"], "%d of %d reads x %d bp (same bytes as the GPU batch)" % (m, n, w["L"])
-    else:
-        if d_len is not None:   # gapped on the device: the oracle takes the same reads packed
-            starts, lens = d_off.cpu().numpy().astype(np.int64), d_len.cpu().numpy().astype(np.int64)
-            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
-            m = int(min(n, np.searchsorted(off, budget_bases)))
-            end = int(starts[m - 1] + lens[m - 1])
-            gs, gq = seq[:end].cpu().numpy(), qual[:end].cpu().numpy()
-            keep = np.zeros(end, dtype=bool)
-            for a, l in zip(starts[:m], lens[:m]):
-                keep[a:a + l] = True
-            hs, hq = gs[keep], gq[keep]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    T = max(1, cores)
+    # one thread: ~3 Gbases (~12 s at 0.25 Gbases/s); T threads: up to the whole batch, twice
+    hs, hq, off, m, bases = host_sample(np, b, w, budget if not threads else 1 << 62)
+    L = w["L"]
+    m1 = m
+    if threads:   # the single-thread leg takes a prefix of the sample
+        if off is None:
+            m1 = min(m, max(1, budget // L))
         else:
-            off = d_off.cpu().numpy().astype(np.uint64)
-            m = int(min(n, np.searchsorted(off, budget_bases)))
-            hs, hq = seq[:int(off[m])].cpu().numpy(), qual[:int(off[m])].cpu().numpy()
-        t0 = time.perf_counter()
-        ob.accumulate_batch(hs, hq, off[:m + 1], kmers=kmers)
-        dt = time.perf_counter() - t0
-        bases, sample = int(off[m]), "%d of %d ragged reads (same bytes as the GPU batch)" % (m, n)
-    return {"value": bases / dt, "unit": "bases/s", "cores": 1, "kind": "port", "sample": sample,
-            "seconds": round(dt, 3), "host": "oracle/quack_oracle.c, single thread (quack is single-threaded)"}
+            m1 = int(min(m, max(1, np.searchsorted(off, budget))))
+
+    def run(lo, hi):
+        if off is None:
+            ob.accumulate_batch(hs[lo * L:hi * L], hq[lo * L:hi * L], read_len=L, kmers=kmers)
+        else:
+            a, e = int(off[lo]), int(off[hi])
+            ob.accumulate_batch(hs[a:e], hq[a:e], (off[lo:hi + 1] - off[lo]), kmers=kmers)
+
+    t0 = time.perf_counter()
+    run(0, m1)
+    dt = time.perf_counter() - t0
+    b1 = m1 * L if off is None else int(off[m1])
+    what = "%d of %d reads" % (m1, b["n"]) + (" x %d bp" % L if off is None else " (ragged)")
+    one = {"value": b1 / dt, "unit": "bases/s", "cores": 1, "kind": "port",
+           "sample": what + " (same bytes as the GPU batch)", "seconds": round(dt, 3),
+           "host": "oracle/quack_oracle.c, single thread (quack is single-threaded)"}
+    if not threads:
+        return one, None
+    # N threads: the sample cut into T contiguous shares, one oracle table per thread (ctypes releases the
+    # GIL); the merge of T small tables is not timed (microseconds)
+    passes = 2
+    cuts = [m * i // T for i in range(T + 1)]
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        th = [threading.Thread(target=run, args=(cuts[i], cuts[i + 1])) for i in range(T) if cuts[i + 1] > cuts[i]]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    dt = time.perf_counter() - t0
+    many = {"value": passes * bases / dt, "unit": "bases/s", "cores": T, "nproc": os.cpu_count(), "kind": "port",
+            "sample": "%d passes over %d of %d reads, cut into %d contiguous shares" % (passes, m, b["n"], T),
+            "seconds": round(dt, 3), "host": "oracle/quack_oracle.c, one table per thread"}
+    return one, many
+
+
+def time_workload(torch, quack_amd, w, b, local, bits, steps, warmup, stream=None):
+    """W + K device-resident passes of one workload on a fresh accumulator -> (roofline dict, table sums)"""
+    acc = quack_amd.Accumulator(local, bits, max_len_hint=b["max_len"])
+
+    def step():
+        if b["d_len"] is not None:
+            acc.submit_device_gapped(b["seq"], b["qual"], b["d_off"], b["d_len"], b["n"], b["extent"], b["max_len"],
+                                     aligned=True, stream=stream)
+        else:
+            acc.submit_device(b["seq"], b["qual"], b["d_off"], b["n"], b["total"], b["max_len"], stream=stream)
+
+    for _ in range(warmup):
+        step()
+    acc.sync()
+    torch.cuda.synchronize()
+    acc.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    acc.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    hist_ms, batch_ms, launches = acc.timing_read_batch()
+    sd = acc.finish()
+    acc.close()
+    got = int(sd.bases[:, 91:95].sum())
+    if got != (warmup + steps) * b["total"]:
+        raise SystemExit("counter check failed (%s): content sum %d != %d" % (w["label"], got, (warmup + steps) * b["total"]))
+    return elapsed, hist_ms / max(launches, 1), batch_ms / max(launches, 1), launches, sd
+
+
+def roofline_of(alg_bytes, kernel_ms, batch_ms, launches, traffic):
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    whole = alg_bytes / (batch_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic else None,
+            "kernel": "qk::hist_kernel", "kernel_ms": kernel_ms,
+            "batch_ms": batch_ms, "frac_whole_batch": whole / HBM_PEAK_GBS,
+            "batch_kernels": "every kernel of a step on the launch stream (reach pre-pass, first-hit reset, hist_kernel, adapter count)",
+            "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    # rehearsal on a one-GPU box: several ranks share one device and the table
-    # exchange goes through gloo (the driver's runs use the defaults: nccl = RCCL)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
-    ap.add_argument("--device", type=int, default=None, help="force this device for every rank")
-    ap.add_argument("--reads", type=int, default=None, help="override reads per GPU (rehearsals)")
-    ap.add_argument("--quality", default="uniform", choices=["uniform", "novaseq4"],
-                    help="novaseq4: Q in {2,12,23,37} with 3/5/12/80 %% (stress for same-bin LDS atomics)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import quack_amd   # fails loudly when the native libraries are missing
+    from quack_amd import distributed as qd
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.device is not None:
         local = args.device
     torch.cuda.set_device(local)
@@ -176,19 +342,22 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    w = dict(WORKLOADS[args.workload])
+    name = args.workload if args.workload != "auto" else ("cfg2" if world == 1 else "cfg4")
+    w = dict(WORKLOADS[name])
     if args.reads:
         w["n"] = args.reads
-    bits, ads = synthetic_adapter_bits() if w["adapters"] else (None, None)
-    seq, qual, d_off, total, max_len, d_len, extent = make_batch(w, seed=2 + rank, device=device, quality=args.quality)
-    n = w["n"]
-    alg_bytes = 2.0 * total + ((12.0 if d_len is not None else 8.0) * n if d_off is not None else 0.0)
+    bits, ads = synthetic_adapter_bits(np) if w["adapters"] else (None, None)
+    b = make_batch(torch, np, w, seed=2 + rank, device=device, quality=args.quality, ads=ads)
+    seq, qual, d_off, d_len = b["seq"], b["qual"], b["d_off"], b["d_len"]
+    total, max_len, extent, n = b["total"], b["max_len"], b["extent"], b["n"]
+    alg_bytes = alg_bytes_of(b)
 
     acc = quack_amd.Accumulator(local, bits, max_len_hint=max_len)
     mate = None
     if w.get("paired"):
         # the reverse mate: its own batch and its own accumulator
-        seq2, qual2, _, _, _, _, _ = make_batch(w, seed=1000 + rank, device=device, quality=args.quality, q_hi_override=30)
+        b2 = make_batch(torch, np, w, seed=1000 + rank, device=device, quality=args.quality, q_hi_override=30)
+        seq2, qual2 = b2["seq"], b2["qual"]
         mate = quack_amd.Accumulator(local, bits, max_len_hint=max_len)
 
     # paired: both mates on ONE stream, so that every launch has the GPU to itself and its
@@ -212,13 +381,14 @@ def main():
         if world > 1:
             dist.barrier()
 
+    via_host = args.backend == "gloo"
     for _ in range(args.warmup):
         step()
     if world > 1:
         # warm the exchange too (communicator, collective kernels) — on a throwaway
         # accumulator, so that the measured tables stay the sum of exactly W+K steps
         with quack_amd.Accumulator(local, None, max_len_hint=max_len) as tmp:
-            qd.allreduce_accumulator(tmp, via_host=args.backend == "gloo")
+            qd.allreduce_accumulator(tmp, via_host=via_host)
     fence()
     acc.timing(True)
     if mate is not None:
@@ -227,20 +397,29 @@ def main():
     for _ in range(args.steps):
         step()
     if world > 1:
-        qd.allreduce_accumulator(acc, via_host=args.backend == "gloo")   # the path's single exchange (RCCL over xGMI)
+        qd.allreduce_accumulator(acc, via_host=via_host)   # the path's single exchange (RCCL over xGMI)
         if mate is not None:
-            qd.allreduce_accumulator(mate, via_host=args.backend == "gloo")
+            qd.allreduce_accumulator(mate, via_host=via_host)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms, launches = acc.timing_read()
+    my_elapsed = elapsed
+    kernel_ms, batch_ms, launches = acc.timing_read_batch()
     mates = 2 if mate is not None else 1
     if mate is not None:
-        ms2, l2 = mate.timing_read()
-        kernel_ms, launches = kernel_ms + ms2, launches + l2
+        ms2, bms2, l2 = mate.timing_read_batch()
+        kernel_ms, batch_ms, launches = kernel_ms + ms2, batch_ms + bms2, launches + l2
+    per_rank = None
+    if world > 1:
+        cd = device if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cd)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        mine = torch.tensor([kernel_ms / max(launches, 1), my_elapsed / args.steps * 1e3, float(local)],
+                            dtype=torch.float64, device=cd)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": i, "device": int(x[2].item()), "kernel_ms": round(float(x[0].item()), 4),
+                     "ms_per_step": round(float(x[1].item()), 4)} for i, x in enumerate(allr)]
 
     # sanity: the counters must add up (every base carries one score and one content bin)
     sd = acc.finish()
@@ -250,18 +429,23 @@ def main():
         expect = (args.warmup + args.steps) * total * world
         if got != expect:
             raise SystemExit("counter check failed: content sum %d != %d" % (got, expect))
+        if sd.number_of_sequences != (args.warmup + args.steps) * n * world:
+            raise SystemExit("counter check failed: %d sequences" % sd.number_of_sequences)
     elif world == 1 and got != (args.warmup + args.steps) * total:
         raise SystemExit("counter check failed: content sum %d" % got)
+    acc.close()
+    if mate is not None:
+        sd2 = mate.finish()
+        if int(sd2.bases[:, 91:95].sum()) != (args.warmup + args.steps) * total * world:
+            raise SystemExit("counter check failed for the reverse mate")
+        mate.close()
 
     if rank == 0:
-        kernel_s = kernel_ms * 1e-3 / max(launches, 1)
-        achieved = alg_bytes / kernel_s / 1e9
-        traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(args.workload)
+        traffic_tab = json.load(open(tf)) if os.path.exists(tf) else {}
+        kms, bms = kernel_ms / max(launches, 1), batch_ms / max(launches, 1)
         out = {
-            "metric": "bases/sec on synthetic 150 bp FASTQ; achieved HBM GB/s vs peak",
+            "metric": METRIC,
             "value": world * args.steps * total * mates / elapsed,
             "unit": "bases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -270,22 +454,38 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": w["label"] + ("" if args.quality == "uniform" else " [quality: %s]" % args.quality),
                        "reads_per_gpu": n * mates, "bases_per_gpu_per_step": total * mates,
-                       "resident": "HBM", "parallelism": "batch-sharded x%d, one all-reduce of u64 tables" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "qk::hist_kernel", "kernel_ms": kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches},
+                       "resident": "HBM", "parallelism": "batch-sharded x%d, one all-reduce of u64 tables%s" % (
+                           world, " per mate" if mate is not None else "")},
+            "roofline": roofline_of(alg_bytes, kms, bms, launches, traffic_tab.get(name)),
         }
+        if world > 1:
+            out["ranks"] = {"world_size": dist.get_world_size(), "backend": "rccl" if args.backend == "nccl" else "gloo (rehearsal)",
+                            "exchange": "%d x all-reduce(SUM, u64) of %d words, inside the timed region" % (
+                                mates, 97 * ((max_len + 63) // 64 * 64) + 1),
+                            "per_rank": per_rank}
+        if world == 1 and args.workload == "auto" and not args.no_also:
+            also = {}
+            for nm in ("cfg3", "cfg5", "trimmed"):
+                w2 = dict(WORKLOADS[nm])
+                bits2, ads2 = synthetic_adapter_bits(np) if w2["adapters"] else (None, None)
+                bb = make_batch(torch, np, w2, seed={"cfg3": 3, "cfg5": 6, "trimmed": 7}[nm], device=device, ads=ads2)
+                el, kms2, bms2, l2, _ = time_workload(torch, quack_amd, w2, bb, local, bits2, args.also_steps, 3)
+                entry = {"workload": w2["label"], "steps": args.also_steps, "value": args.also_steps * bb["total"] / el,
+                         "unit": "bases/s", "ms_per_step": el / args.also_steps * 1e3,
+                         "roofline": roofline_of(alg_bytes_of(bb), kms2, bms2, l2, traffic_tab.get(nm))}
+                if nm == "cfg3":
+                    entry["reads_with_spliced_adapter"] = bb["spliced"]
+                if not args.no_cpu_baseline:
+                    entry["cpu_baseline"], _ = cpu_baselines(np, bb, w2, ads2, threads=False, budget=1_500_000_000)
+                also[nm] = entry
+                del bb
+                torch.cuda.empty_cache()
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seq, qual, d_off, n, total, w, ads, d_len)
+            out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baselines(np, b, w, ads)
         print(json.dumps(out), flush=True)
-    acc.close()
-    if mate is not None:
-        sd2 = mate.finish()
-        if int(sd2.bases[:, 91:95].sum()) != (args.warmup + args.steps) * total * world:
-            raise SystemExit("counter check failed for the reverse mate")
-        mate.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

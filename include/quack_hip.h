@@ -168,10 +168,26 @@ int qk_accum_finish(qk_accum *acc, qk_base_info *out, uint64_t cap_positions,
  * last reset, measured with hipEvents on the launch stream. */
 int qk_accum_timing_enable(qk_accum *acc, int on);
 int qk_accum_timing_read(qk_accum *acc, double *total_ms, uint64_t *launches);
+/* Same, plus the time of ALL kernels of the batches (reach pre-pass, length
+ * kernel, first-hit reset, histogram, adapter count): hist_ms <= batch_ms. */
+int qk_accum_timing_read_batch(qk_accum *acc, double *hist_ms, double *batch_ms,
+                               uint64_t *launches);
 
 /* ---- tuning knobs (env: QUACK_HIP_THREADS / _UNROLL / _TILE) ---------- */
 int qk_accum_configure(qk_accum *acc, int threads_per_wg, int unroll,
                        int tile_positions, int wgs_per_cu);
+
+/* ---- diagnostics (tests/test_planner.py, tools/kbench; no reference counterpart) -- */
+/* Launch geometry the planner would choose for a batch shape; needs no device.
+ * out[16]: n_tiles, tile_pos, chunks, reads/iter, unroll, pipe, reads/slice,
+ * n_slices, n_blocks, LDS bytes, halo, fused, dynamic, aligned, replicas,
+ * row dwords. */
+int qk_debug_plan(uint64_t n_reads, uint32_t max_len, int ragged, int adapters,
+                  uint32_t bucket_log2, int gapped, int aligned, int n_cu,
+                  uint64_t *out);
+/* Ablation builds of the histogram kernel (-DQK_ABLATION, tools/kbench only);
+ * the product library only has mode 0 and rejects any other at launch. */
+int qk_debug_set_mode(int mode);
 
 #ifdef __cplusplus
 }

@@ -76,6 +76,7 @@ def hip():
     L.qk_accum_finish.argtypes = [c_vp, c_vp, ctypes.c_uint64, c_u64p, c_u64p]
     L.qk_accum_timing_enable.argtypes = [c_vp, ctypes.c_int]
     L.qk_accum_timing_read.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double), c_u64p]
+    L.qk_accum_timing_read_batch.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_u64p]
     L.qk_accum_configure.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     _hip = L
     return L

@@ -231,6 +231,12 @@ class Accumulator:
         _check(self._L.qk_accum_timing_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+    def timing_read_batch(self):
+        """(histogram-kernel ms, all-kernels-of-the-batch ms, launches) since timing(True)"""
+        ms, bms, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
+        _check(self._L.qk_accum_timing_read_batch(self._h, ctypes.byref(ms), ctypes.byref(bms), ctypes.byref(n)))
+        return ms.value, bms.value, n.value
+
     def finish(self):
         a, b = ctypes.c_uint64(), ctypes.c_uint64()
         _check(self._L.qk_accum_finish(self._h, None, 0, ctypes.byref(a), ctypes.byref(b)))

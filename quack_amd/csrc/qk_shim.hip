@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <set>
@@ -66,7 +67,8 @@ struct Slot {
 };
 
 struct TimedLaunch {
-  hipEvent_t t0, t1;
+  hipEvent_t t0, t1;   // around the histogram kernel (the dominant kernel)
+  hipEvent_t b0, b1;   // around every kernel of the batch (pre-pass ... adapter count); may alias t0 / t1
 };
 
 }  // namespace
@@ -115,7 +117,7 @@ struct qk_accum {
   bool timing = false;
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> event_pool;
-  double timing_ms = 0;
+  double timing_ms = 0, timing_batch_ms = 0;
   uint64_t timing_launches = 0;
 };
 
@@ -386,6 +388,22 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   rc = make_plan(a, n_reads, max_len, d_off != nullptr, d_len != nullptr, d_len && (flags & QK_BATCH_ALIGNED128), &pl);
   if (rc) return rc;
   if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));
+  TimedLaunch tl{};
+  if (a->timing) {
+    tl.t0 = get_event(a);
+    tl.t1 = get_event(a);
+    if (!tl.t0 || !tl.t1) return fail(QK_EHIP, "hipEventCreate failed");
+    tl.b0 = tl.t0;
+    tl.b1 = tl.t1;
+    // batches with a pre-pass (queue reset, reach sort, length kernel) or an adapter
+    // count kernel get their own pair of events around the whole batch
+    if (pl.n_tiles > 1 || a->adapters) {
+      tl.b0 = get_event(a);
+      tl.b1 = get_event(a);
+      if (!tl.b0 || !tl.b1) return fail(QK_EHIP, "hipEventCreate failed");
+      QK_HIP(hipEventRecord(tl.b0, st));
+    }
+  }
   qk::HistParams hp{};
   hp.seq = d_seq;
   hp.qual = d_qual;
@@ -466,24 +484,19 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.replicas = qk::hist_replicas(pl.ch, pl.fused_adapters);
   hp.halo = pl.halo;
 
-  TimedLaunch tl{};
-  if (a->timing) {
-    tl.t0 = get_event(a);
-    tl.t1 = get_event(a);
-    if (!tl.t0 || !tl.t1) return fail(QK_EHIP, "hipEventCreate failed");
-    QK_HIP(hipEventRecord(tl.t0, st));
-  }
+  if (a->timing) QK_HIP(hipEventRecord(tl.t0, st));
   if (pl.fused_adapters) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
   rc = launch_hist(a, hp, pl, d_off == nullptr, g_ablation_mode, pl.fused_adapters, st);
   if (rc) return rc;
-  if (a->timing) {
-    QK_HIP(hipEventRecord(tl.t1, st));
-    a->timed.push_back(tl);
-  }
+  if (a->timing) QK_HIP(hipEventRecord(tl.t1, st));
   if (a->adapters) {
     // fused: the histogram pass already left first_hit[]; otherwise scan now
     rc = pl.fused_adapters ? qk::launch_adapter_count(hp, a->n_cu, st) : qk::launch_adapter_scan(hp, a->n_cu, st);
     if (rc) return fail(QK_EHIP, "adapter kernels failed: %s", hipGetErrorString((hipError_t)rc));
+  }
+  if (a->timing) {
+    if (tl.b1 != tl.t1) QK_HIP(hipEventRecord(tl.b1, st));
+    a->timed.push_back(tl);
   }
   QK_HIP(hipEventRecord(a->order_ev, st));
   a->order_stream = st;
@@ -495,13 +508,20 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
 
 int drain_timing(qk_accum *a) {
   for (auto &tl : a->timed) {
-    float ms = 0;
-    QK_HIP(hipEventSynchronize(tl.t1));
+    float ms = 0, bms = 0;
+    QK_HIP(hipEventSynchronize(tl.b1));
     QK_HIP(hipEventElapsedTime(&ms, tl.t0, tl.t1));
+    bms = ms;
+    if (tl.b0 != tl.t0) QK_HIP(hipEventElapsedTime(&bms, tl.b0, tl.b1));
     a->timing_ms += ms;
+    a->timing_batch_ms += bms;
     a->timing_launches += 1;
     a->event_pool.push_back(tl.t0);
     a->event_pool.push_back(tl.t1);
+    if (tl.b0 != tl.t0) {
+      a->event_pool.push_back(tl.b0);
+      a->event_pool.push_back(tl.b1);
+    }
   }
   a->timed.clear();
   return QK_OK;
@@ -512,6 +532,94 @@ int set_device(const qk_accum *a) {
   return QK_OK;
 }
 
+}  // namespace
+
+// ---- RCCL (loaded on first use; libquack_hip.so itself does not link it) ----
+// The two mates of a pair are accumulated by two host threads (cli.c), and both
+// end in qk_accum_allreduce over the same devices.  Everything RCCL — loading the
+// library, creating communicators, the collective and the wait for it — therefore
+// runs under ONE process-wide lock: two ncclCommInitAll over the same devices at
+// the same time, or two collectives on different communicators enqueued in a
+// different order on different devices, are the classic multi-communicator hangs.
+// Communicators are created once per device set and kept for the life of the
+// process (a file pair would otherwise pay the ~100 ms of ncclCommInitAll twice).
+typedef struct ncclComm *ncclComm_t;
+namespace {
+struct RcclApi {
+  int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*GroupStart)(void) = nullptr;
+  int (*GroupEnd)(void) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  char why[256] = "";
+  bool ok = false;
+};
+constexpr int kNcclUint64 = 5, kNcclSum = 0;   // rccl.h: ncclUint64 = 5 (ncclDataType_t), ncclSum = 0 (ncclRedOp_t)
+
+RcclApi g_rccl;
+std::once_flag g_rccl_once;
+std::mutex g_rccl_mu;                                      // serialises every RCCL section of the process
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_rccl_comms;   // device set -> communicators (guarded by g_rccl_mu)
+
+const RcclApi &rccl_api() {
+  std::call_once(g_rccl_once, [] {
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+      const char *e = dlerror();
+      snprintf(g_rccl.why, sizeof g_rccl.why, "cannot load librccl.so: %s", e ? e : "?");
+      return;
+    }
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(lib, "ncclCommInitAll");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(lib, "ncclGroupEnd");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.CommInitAll || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.GetErrorString) {
+      snprintf(g_rccl.why, sizeof g_rccl.why, "librccl.so lacks a required symbol");
+      return;
+    }
+    g_rccl.ok = true;
+  });
+  return g_rccl;
+}
+
+// One all-reduce(SUM, u64) of `words` table words over the accumulators `who`
+// (distinct devices).  Caller holds nothing; this takes g_rccl_mu.
+int rccl_sum_tables(qk_accum **who, int n, size_t words) {
+  const RcclApi &api = rccl_api();
+  if (!api.ok) return fail(QK_ERCCL, "%s", api.why);
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) devs[i] = who[i]->device;
+  auto it = g_rccl_comms.find(devs);
+  if (it == g_rccl_comms.end()) {
+    std::vector<ncclComm_t> comms(n);
+    const int e = api.CommInitAll(comms.data(), n, devs.data());
+    if (e) return fail(QK_ERCCL, "ncclCommInitAll: %s", api.GetErrorString(e));
+    it = g_rccl_comms.emplace(devs, std::move(comms)).first;
+  }
+  const std::vector<ncclComm_t> &comms = it->second;
+  int e = api.GroupStart();
+  if (e) return fail(QK_ERCCL, "ncclGroupStart: %s", api.GetErrorString(e));
+  for (int i = 0; i < n && !e; ++i) {
+    (void)hipSetDevice(who[i]->device);
+    e = api.AllReduce(who[i]->d_table, who[i]->d_table, words, kNcclUint64, kNcclSum, comms[i], who[i]->stream);
+  }
+  const int e2 = api.GroupEnd();
+  if (!e) e = e2;
+  // the lock is held until the collective has finished on every device: the next
+  // caller's collective (same communicators, other streams) must not overtake it
+  hipError_t he = hipSuccess;
+  for (int i = 0; i < n; ++i) {
+    (void)hipSetDevice(who[i]->device);
+    const hipError_t h = hipStreamSynchronize(who[i]->stream);
+    if (he == hipSuccess) he = h;
+  }
+  if (e) return fail(QK_ERCCL, "ncclAllReduce: %s", api.GetErrorString(e));
+  if (he != hipSuccess) return fail(QK_EHIP, "waiting for the all-reduce: %s", hipGetErrorString(he));
+  return QK_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -646,6 +754,10 @@ void qk_accum_destroy(qk_accum *a) {
   for (auto &tl : a->timed) {
     (void)hipEventDestroy(tl.t0);
     (void)hipEventDestroy(tl.t1);
+    if (tl.b0 != tl.t0) {
+      (void)hipEventDestroy(tl.b0);
+      (void)hipEventDestroy(tl.b1);
+    }
   }
   for (auto e : a->event_pool) (void)hipEventDestroy(e);
   if (a->d_queues) (void)hipFree(a->d_queues);
@@ -961,14 +1073,6 @@ int qk_accum_import_table(qk_accum *a, const void *d_src, uint64_t max_len, void
   return QK_OK;
 }
 
-// ---- RCCL (loaded on first use; libquack_hip.so itself does not link it) ----
-typedef struct ncclComm *ncclComm_t;
-typedef int (*fn_CommInitAll)(ncclComm_t *, int, const int *);
-typedef int (*fn_AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t);
-typedef int (*fn_Void)(void);
-typedef int (*fn_CommDestroy)(ncclComm_t);
-typedef const char *(*fn_ErrStr)(int);
-
 int qk_accum_allreduce(qk_accum **accs, int n) {
   if (!accs || n <= 0) return fail(QK_EINVAL, "bad arguments");
   for (int i = 0; i < n; ++i)
@@ -1018,40 +1122,14 @@ int qk_accum_allreduce(qk_accum **accs, int n) {
     QK_HIP(hipStreamSynchronize(accs[l]->stream));
   }
   // 2) distinct devices: ONE all-reduce of the integer tables over xGMI
+  //    (QUACK_HIP_RCCL_ALWAYS=1: also with a single device — lets a one-GPU box
+  //    exercise the RCCL call sequence, tests/test_gpu_multi.py)
   const int nl = (int)leaders.size();
-  if (nl > 1) {
-    static void *lib = nullptr;
-    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib) return fail(QK_ERCCL, "cannot load librccl.so: %s", dlerror());
-    fn_CommInitAll init = (fn_CommInitAll)dlsym(lib, "ncclCommInitAll");
-    fn_AllReduce allreduce = (fn_AllReduce)dlsym(lib, "ncclAllReduce");
-    fn_Void gstart = (fn_Void)dlsym(lib, "ncclGroupStart");
-    fn_Void gend = (fn_Void)dlsym(lib, "ncclGroupEnd");
-    fn_CommDestroy cdestroy = (fn_CommDestroy)dlsym(lib, "ncclCommDestroy");
-    fn_ErrStr errstr = (fn_ErrStr)dlsym(lib, "ncclGetErrorString");
-    if (!init || !allreduce || !gstart || !gend || !cdestroy || !errstr)
-      return fail(QK_ERCCL, "librccl.so lacks a required symbol");
-    std::vector<ncclComm_t> comms(nl);
-    std::vector<int> devs(nl);
-    for (int i = 0; i < nl; ++i) devs[i] = accs[leaders[i]]->device;
-    int e = init(comms.data(), nl, devs.data());
-    if (e) return fail(QK_ERCCL, "ncclCommInitAll: %s", errstr(e));
-    const int kNcclUint64 = 5, kNcclSum = 0;  // rccl.h: ncclUint64 = 5, ncclSum = 0
-    e = gstart();
-    for (int i = 0; i < nl && !e; ++i) {
-      qk_accum *a = accs[leaders[i]];
-      (void)hipSetDevice(a->device);
-      e = allreduce(a->d_table, a->d_table, words, kNcclUint64, kNcclSum, comms[i], a->stream);
-    }
-    int e2 = gend();
-    if (!e) e = e2;
-    for (int i = 0; i < nl; ++i) {
-      (void)hipSetDevice(accs[leaders[i]]->device);
-      (void)hipStreamSynchronize(accs[leaders[i]]->stream);
-    }
-    for (int i = 0; i < nl; ++i) cdestroy(comms[i]);
-    if (e) return fail(QK_ERCCL, "ncclAllReduce: %s", errstr(e));
+  if (nl > 1 || getenv("QUACK_HIP_RCCL_ALWAYS")) {
+    std::vector<qk_accum *> who(nl);
+    for (int i = 0; i < nl; ++i) who[i] = accs[leaders[i]];
+    const int rc = rccl_sum_tables(who.data(), nl, words);
+    if (rc) return rc;
   }
   // 3) every accumulator ends up holding the global table
   for (int i = 0; i < n; ++i) {
@@ -1092,15 +1170,21 @@ int qk_accum_timing_enable(qk_accum *a, int on) {
   if (!a) return fail(QK_EINVAL, "acc is NULL");
   a->timing = on != 0;
   a->timing_ms = 0;
+  a->timing_batch_ms = 0;
   a->timing_launches = 0;
   return QK_OK;
 }
 
 int qk_accum_timing_read(qk_accum *a, double *total_ms, uint64_t *launches) {
+  return qk_accum_timing_read_batch(a, total_ms, nullptr, launches);
+}
+
+int qk_accum_timing_read_batch(qk_accum *a, double *hist_ms, double *batch_ms, uint64_t *launches) {
   if (!a) return fail(QK_EINVAL, "acc is NULL");
   int rc = drain_timing(a);
   if (rc) return rc;
-  if (total_ms) *total_ms = a->timing_ms;
+  if (hist_ms) *hist_ms = a->timing_ms;
+  if (batch_ms) *batch_ms = a->timing_batch_ms;
   if (launches) *launches = a->timing_launches;
   return QK_OK;
 }

@@ -74,24 +74,6 @@ static int is_opt(const char *arg, const char *s, const char *l) {
   return strcmp(arg, s) == 0 || strcmp(arg, l) == 0;
 }
 
-static int parse_device_list(int *devs, int cap) {
-  const char *env = getenv("QUACK_DEVICES");
-  int n = 0;
-  if (!env || !*env) {
-    devs[0] = 0;
-    return 1;
-  }
-  while (*env && n < cap) {
-    char *end;
-    long v = strtol(env, &end, 10);
-    if (end == env) break;
-    devs[n++] = (int)v;
-    env = *end == ',' ? end + 1 : end;
-  }
-  if (n == 0) devs[n++] = 0;
-  return n;
-}
-
 int qkh_main(int argc, char **argv) {
   options o = {0};
   uint32_t *bitset = NULL;
@@ -135,7 +117,7 @@ int qkh_main(int argc, char **argv) {
       goto done;
     }
   }
-  n_devs = parse_device_list(devs, 64);
+  n_devs = qkh_device_list(devs, 64);
 
   /* accumulate first (quack.c:911,917), print afterwards */
   {

@@ -35,6 +35,26 @@ static double now_s(void) {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+/* QUACK_DEVICES=0,1,... -> device ids (default: device 0).  Environment only:
+ * the command line stays the reference's (quack.c:59-132). */
+int qkh_device_list(int *devs, int cap) {
+  const char *env = getenv("QUACK_DEVICES");
+  int n = 0;
+  if (!env || !*env) {
+    devs[0] = 0;
+    return 1;
+  }
+  while (*env && n < cap) {
+    char *end;
+    long v = strtol(env, &end, 10);
+    if (end == env) break;
+    devs[n++] = (int)v;
+    env = *end == ',' ? end + 1 : end;
+  }
+  if (n == 0) devs[n++] = 0;
+  return n;
+}
+
 int qkh_accumulate_file(const char *path, const uint32_t *bitset,
                         const int *devices, int n_devices,
                         qk_base_info **bases_out, uint64_t *max_len,

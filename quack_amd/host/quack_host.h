@@ -63,6 +63,8 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
                         qk_base_info **bases_out, uint64_t *max_len,
                         uint64_t *n_reads);
 const char *qkh_last_error(void);
+/* device ids from QUACK_DEVICES (comma separated; default: 0); returns how many */
+int qkh_device_list(int *devs, int cap);
 
 /* ---- post-processing and SVG --------------------------------------------- */
 typedef struct {

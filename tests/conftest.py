@@ -17,6 +17,7 @@ def _build_if_missing():
     need_oracle = not os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))
     need_native = not (os.path.exists(os.path.join(ROOT, "quack_amd", "libquack_hip.so"))
                        and os.path.exists(os.path.join(ROOT, "quack_amd", "libquack_host.so"))
+                       and os.path.exists(os.path.join(ROOT, "quack_amd", "libquack_dropin.so"))
                        and os.path.exists(os.path.join(ROOT, "quack_amd", "host", "quack")))
     if need_oracle:
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
