@@ -320,6 +320,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    # stdout carries exactly ONE JSON line: anything a library prints there (RCCL logs its
+    # version banner and NCCL_DEBUG output to stdout) goes to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -483,7 +489,7 @@ def main():
             out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baselines(np, b, w, ads)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -160,7 +160,8 @@ inline int launch_adapter_scan(const HistParams &hp, int n_cu, hipStream_t st) {
   return launch_adapter_count(hp, n_cu, st);
 }
 
-// Build the LDS-resident exact table of the fused path: 2^log2b buckets of
+// Build the LDS-resident exact table of the fused path (the queued candidates are
+// checked against it without leaving the LDS): 2^log2b buckets of
 // eight u16 slots, keyed by km*mul mod 2^20.  Returns false when no (mul, size)
 // up to `max_log2` avoids a bucket overflow (very large adapter sets): the
 // kernel then falls back to the global bitset for filter hits.
@@ -204,13 +205,16 @@ inline bool build_kmer_buckets(const uint32_t *host_bits, uint32_t max_log2, std
   return false;
 }
 
-// Upload the exact bitset and derive the LDS pre-filter from it.
+// Upload the exact bitset and derive the LDS filters from it:
+//   words [0, 2^13)      separate scan kernel: 2^18 bits keyed by a window's low 18 bits
+//   words [2^13, 2^14)   fused path: 2^18 bits holding, for every adapter 10-mer, its
+//                        prefix 9-mer and its suffix 9-mer, over COMPLEMENTED codes
+//                        (hist_kernel probes the one 9-mer of a window that ends on an
+//                        even position; byte = key >> 3, bit = key & 7, as it reads it)
 inline int upload_kmer_tables(const uint32_t *host_bits, uint32_t **d_bits, uint32_t **d_filter,
                               uint32_t *filter_bits) {
   const uint32_t words = 1u << 15;  // 2^20 bits
-  // [first level: 2^18 bits by the window's low 18 bits | second level (fused
-  // path only): 2^17 bits by its top 17 bits]
-  uint32_t *filt = (uint32_t *)calloc(kFusedFilterWords, sizeof(uint32_t));
+  uint32_t *filt = (uint32_t *)calloc(2u * kFusedFilterWords, sizeof(uint32_t));
   if (!filt) return (int)hipErrorOutOfMemory;
   for (uint32_t w = 0; w < words; ++w) {
     uint32_t v = host_bits[w];
@@ -220,14 +224,15 @@ inline int upload_kmer_tables(const uint32_t *host_bits, uint32_t **d_bits, uint
       const uint32_t km = w * 32u + b;
       const uint32_t h = km & (kFilterBits - 1u);
       filt[h >> 5] |= 1u << (h & 31u);
-      const uint32_t h2 = km >> 3;   // 17 bits; byte h2 >> 3, bit h2 & 7 — as the kernel reads it
-      filt[kFilterBits / 32 + (h2 >> 5)] |= 1u << (h2 & 31u);
+      const uint32_t suffix9 = (km & 0x3FFFFu) ^ 0x3FFFFu, prefix9 = (km >> 2) ^ 0x3FFFFu;
+      filt[kFusedFilterWords + (suffix9 >> 5)] |= 1u << (suffix9 & 31u);
+      filt[kFusedFilterWords + (prefix9 >> 5)] |= 1u << (prefix9 & 31u);
     }
   }
   hipError_t e = hipMalloc((void **)d_bits, words * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemcpy(*d_bits, host_bits, words * sizeof(uint32_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc((void **)d_filter, kFusedFilterWords * 4);
-  if (e == hipSuccess) e = hipMemcpy(*d_filter, filt, kFusedFilterWords * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void **)d_filter, 2u * kFusedFilterWords * 4);
+  if (e == hipSuccess) e = hipMemcpy(*d_filter, filt, 2u * kFusedFilterWords * 4, hipMemcpyHostToDevice);
   free(filt);
   *filter_bits = kFilterBits;
   return (int)e;

@@ -29,10 +29,14 @@
 //     give 2-bit codes, 8 of them packed per chunk; the 9 predecessor codes come
 //     from lanes -1 / -2 by DPP wave_shr:1 (two feeder lanes per wave re-compute
 //     the previous wave's last chunks; with several tiles two halo lanes per
-//     read row cover the 16 positions before the tile); each of the 8 windows
-//     probes a two-level bit filter at LDS byte 0, and only what passes both
-//     consults the exact table (LDS buckets of 15-bit remainders, or the global
-//     2^20-bit set for huge adapter files); atomicMin(first_hit[read]).
+//     read row cover the 16 positions before the tile).  Every 10-mer window
+//     contains exactly one 9-mer that ends on an even position, so the lane
+//     probes FOUR 9-mers per chunk (not eight windows) in a 2^18-bit filter at
+//     LDS byte 0 that holds the prefix and the suffix 9-mer of every adapter
+//     10-mer; what passes (~2 % of the lanes, almost all false positives) goes
+//     into a per-wave LDS queue and is checked against the exact 2^20-bit table
+//     a wave's worth at a time (checking on the spot would issue the check for
+//     the whole wave in four steps out of five); atomicMin(first_hit[read]).
 //   * long reads: position tiles x read slices; persistent workgroups pull
 //     slices from per-tile device counters and flush only when they change
 //     tile.  Batches whose reads start on 128-byte lines (AL) get tiles of whole
@@ -73,7 +77,7 @@ struct HistParams {
   unsigned long long *table;    // planar [kOutRows][table_len]
   uint32_t *first_hit;          // per-read first adapter hit (ADAPT only)
   const uint32_t *kmer_bits;    // 2^20-bit exact table (ADAPT only)
-  const uint32_t *kmer_filter;  // 2^18-bit window filter, copied into LDS (ADAPT only)
+  const uint32_t *kmer_filter;  // [2^18 bits: suffix 9-mers (separate scan kernel) | 2^18 bits: the fused path's filter, copied into LDS]
   uint64_t n_reads;
   uint64_t total_bytes;         // offsets[n_reads]; loads are clamped to it
   uint64_t reads_per_slice;     // <= kMaxReadsPerSlice
@@ -89,8 +93,9 @@ struct HistParams {
   uint32_t n_slices;            // read slices per tile; work items = n_tiles * n_slices
   uint32_t *queue;              // [n_tiles] slice counters (several tiles), or NULL
   uint32_t no_adapters;         // kmers == NULL semantics (quack.c:210,215)
-  // exact LDS-resident membership table for the fused adapter path (0: use the
-  // global bitset): 2^bucket_log2 buckets of eight u16 remainders
+  // exact LDS-resident membership table the queued candidates are checked against (0: the
+  // global 2^20-bit table — huge adapter files, or no room): 2^bucket_log2 buckets of eight
+  // u16 remainders
   const uint4 *kmer_buckets;
   uint32_t bucket_log2;
   uint32_t bucket_mul;          // odd multiplier: km' = km * mul mod 2^20 is a bijection
@@ -100,8 +105,9 @@ struct HistParams {
 struct u32x3 { uint32_t x, y, z; };
 // 8 bytes from an 8-byte-aligned address (batches whose reads start on cache
 // lines: the chunk is aligned as it is)
+struct u32x2 { uint32_t x, y; };   // (4-byte alignment: one global_load_dwordx2 all the same)
 __device__ __forceinline__ u32x3 load8_aligned(const uint8_t *p) {
-  const uint2 v = *reinterpret_cast<const uint2 *>(p);
+  const u32x2 v = *reinterpret_cast<const u32x2 *>(__builtin_assume_aligned(p, 4));
   return u32x3{v.x, v.y, 0u};
 }
 __device__ __forceinline__ u32x3 load12_aligned(const uint8_t *p) {
@@ -153,18 +159,28 @@ inline __host__ __device__ uint32_t hist_replicas(uint32_t ch, bool adapt = fals
 inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch, bool adapt = false) {
   return (4u * hist_replicas(ch, adapt) * ch + 31u) / 32u * 32u;
 }
-constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit window filter = 32 KiB of LDS, keyed by the window's low 18 bits
-constexpr uint32_t kFusedFilter2Log2 = 17;  // second level, 16 KiB, keyed by the window's top 17 bits
-constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u + (1u << kFusedFilter2Log2) / 32u;
+constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit 9-mer filter = 32 KiB of LDS
+constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr uint32_t kStageReads = 1024;      // ragged: read descriptors staged in LDS per pass (at least; HistParams::stage_reads)
 constexpr uint32_t kStageReadsMax = 8192;
+// Candidate queue of the fused adapter path: what passes the 9-mer filter (a lane
+// or two per wave and step, nearly all false positives) is not checked on the
+// spot — that would issue the check's instructions for the whole wave, and the
+// kernel is VALU-bound — but appended to a per-wave queue in LDS and checked
+// against the exact table when the queue holds a wave's worth of entries.
+constexpr uint32_t kCandCap = 96;                       // entries per wave: drained above 32, a step adds <= 64
+constexpr uint32_t kCandWords = 16u * kCandCap * 2u;    // 16 waves x 96 entries x 8 bytes = 12 KiB
 inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false,
                              uint32_t stage_reads = kStageReads) {
-  return ((size_t)kQRows * hist_row_dwords(ch, adapt) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords : 0u)) * sizeof(uint32_t) +
+  return ((size_t)kQRows * hist_row_dwords(ch, adapt) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords + kCandWords : 0u)) * sizeof(uint32_t) +
          (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)stage_reads * (adapt ? 12 : 8) : 0);
 }
 
+// The fused path works on COMPLEMENTED 2-bit codes (3 - code: the "not T / not C /
+// not G" indicators give them without an inversion), so its keys are the
+// reference's 10-mer indices (quack.c:150,208) xor 0xFFFFF.
+constexpr uint32_t kKmerMask = 0xFFFFFu;
 // Exact membership in the bucket table: km' = km*mul mod 2^20 (a bijection for
 // odd mul); the top bucket_log2 bits pick a 16-byte bucket, the rest (< 2^15)
 // is stored with bit 15 set.  Empty slots are 0.
@@ -209,15 +225,18 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 #ifndef QK_MIN_WAVES_PER_SIMD
 #define QK_MIN_WAVES_PER_SIMD 1   // experiments: (T/256)*k asks for k workgroups per CU
 #endif
-// AL (ragged only): every read of the batch starts on a 128-byte boundary, so a
+// AL, ragged: every read of the batch starts on a 128-byte boundary, so a
 // lane's chunk is 8-byte aligned and a 512-position tile of a read is exactly
 // four cache lines (see QK_BATCH_ALIGNED128 in quack_hip.h).
+// AL, fixed length: read_len is a multiple of 4 (36, 76, 100, 300 ...), so every
+// chunk starts on a dword: one global_load_dwordx2, no 12-byte window, no
+// v_alignbyte.
 template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false>
 __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
   extern __shared__ uint32_t lds_raw[];
   // ADAPT: the window filter sits first, so that the probes' LDS addresses are
   // "field + constant" (no per-probe add of a layout-dependent base)
-  uint32_t *lds = lds_raw + (ADAPT ? kFusedFilterWords : 0u);
+  uint32_t *lds = lds_raw + (ADAPT ? kFusedFilterWords + kCandWords : 0u);
   const uint32_t tid = threadIdx.x;
   const uint32_t CH = p.ch;
   const uint32_t RD = p.row_dwords;
@@ -229,10 +248,10 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   uint32_t *lds_filter = lds_raw;         // ADAPT only
   const uint8_t *filt8 = reinterpret_cast<const uint8_t *>(lds_raw);   // == LDS byte 0, see lds_abs_u8
   (void)filt8;
-  // (the filter, hist words, 5*TP and 4 are all multiples of 4 dwords: 16-byte aligned)
-  uint4 *lds_buckets = reinterpret_cast<uint4 *>(lds_misc + 4u);
   // ragged batches: descriptors {start - slice base, length [| index << 16]} of
   // the reads of the current pass that reach this tile, compacted
+  // (the filter, hist words, 5*TP and 4 are all multiples of 4 dwords: 16-byte aligned)
+  uint4 *lds_buckets = reinterpret_cast<uint4 *>(lds_misc + 4u);
   uint2 *lds_list = reinterpret_cast<uint2 *>(
       reinterpret_cast<char *>(lds_misc + 4u) + ((ADAPT && p.bucket_log2) ? (16u << p.bucket_log2) : 0u));
   const uint32_t SR = FIXED ? kStageReads : p.stage_reads;
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   const uint64_t TL = p.table_len;
 
   if (ADAPT) {
-    for (uint32_t i = tid; i < kFusedFilterWords; i += T) lds_filter[i] = p.kmer_filter[i];
+    for (uint32_t i = tid; i < kFusedFilterWords; i += T) lds_filter[i] = p.kmer_filter[kFusedFilterWords + i];
     if (p.bucket_log2)
       for (uint32_t i = tid; i < (1u << p.bucket_log2); i += T) lds_buckets[i] = p.kmer_buckets[i];
   }
@@ -249,6 +268,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   // of the previous wave's lanes 62/63 so that lanes 2/3 find their
   // predecessors' codes by DPP; they take no part in the histograms.
   const uint32_t lane_id = tid & 63u;
+  const uint32_t lane10 = lane_id << 10;
   const uint32_t feeders = ADAPT ? 2u : 0u;
   const int32_t slot_signed = (int32_t)((tid >> 6) * (64u - feeders) + lane_id) - (int32_t)feeders;
   const uint32_t slot = slot_signed < 0 ? 0u : (uint32_t)slot_signed;
@@ -272,6 +292,9 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   for (int jj = 0; jj < 4; ++jj) qcol[jj] = ((jj * R + ri % R) * CH + ch) * 4u;
   const uint32_t one_lo = 1u, one_hi = 65536u;
 
+  // ADAPT: this wave's candidate queue (see kCandCap) and its fill (wave-uniform)
+  uint2 *cand_q = reinterpret_cast<uint2 *>(lds_raw + kFusedFilterWords) + (tid >> 6) * kCandCap;
+  uint32_t cand_n = 0;
   uint32_t n_gt10 = 0;        // reads longer than 10 (kmers==NULL path, quack.c:215)
   uint32_t fixed_reads = 0;   // FIXED, tile 0: reads seen since the last flush
   uint32_t keep = 0;          // MODE 1 only
@@ -422,8 +445,6 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
       fm0 = nc >= 4u ? 0u : (0xFFFFFFFFu << (8u * nc));
       fm1 = nc >= 8u ? 0u : (nc <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (nc - 4u))));
     }
-    // windows ending before position 9 do not exist
-    const uint32_t win_mask = cpos >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cpos)) - 1u));
 
     // Fixed-length batches: one pass over the slice, read r at r*L.  Ragged
     // batches: passes of stage_reads reads; each pass first stages, in LDS, the
@@ -525,32 +546,29 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
       // before its ds_adds), so that the LDS read does not queue behind a
       // step's 32 atomics when the next global loads want to start.
       uint2 de[U];
-      uint32_t dr[U];
       auto load_desc = [&](uint32_t it) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t rel = it + (uint32_t)u * RW + ri;
           const bool in_list = rel < n_list && ri < RW;
           de[u] = lds_list[in_list ? rel : 0u];
-          dr[u] = ADAPT ? lds_ridx[in_list ? rel : 0u] : 0u;
         }
       };
       auto issue = [&](uint32_t it, u32x3 (&q)[U], u32x3 (&s)[U], uint32_t (&nv)[U], uint32_t (&sk)[U],
-                       uint32_t (&ridx)[U]) __attribute__((always_inline)) {
+                       uint32_t (&rl)[U]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t rel = it + (uint32_t)u * RW + ri;   // index into the slice (FIXED) / the staged list
+          rl[u] = rel;
           const bool in_list = rel < n_list && ri < RW;
           uint32_t off, len;
           if (FIXED) {
             off = rel * p.read_len + cposp;
             len = p.read_len;
-            ridx[u] = (uint32_t)r_begin + rel;
           } else {
             const uint2 e = PD > 1 ? lds_list[in_list ? rel : 0u] : de[u];
             off = e.x + cpos;
             len = e.y;
-            ridx[u] = ADAPT ? (PD > 1 ? lds_ridx[in_list ? rel : 0u] : dr[u]) : 0u;
           }
           // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
           // compute codes like their originals but count nothing
@@ -559,8 +577,12 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           nv[u] = lane_on ? n_raw : 0u;
           off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
           sk[u] = AL ? 0u : (off & 3u);
-          off &= AL ? ~7u : ~3u;
-          if (AL) {
+          off &= (AL && !FIXED) ? ~7u : ~3u;
+          if (AL && FIXED) {
+            // read_len is a multiple of 4: every chunk starts on a dword
+            q[u] = load8_aligned(qbase + off);
+            s[u] = load8_aligned(sbase + off);
+          } else if (AL) {
             q[u] = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             s[u] = q[u];
             if (n_raw != 0) {
@@ -581,20 +603,69 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           }
         }
       };
+      // Exact check of the queued candidates {plo, prev2 | hits << 2 | lane << 10 | rel << 16}, one entry per
+      // lane.  Position and length of the chunk come back from the lane that queued it (ds_bpermute)
+      // and from the read's descriptor: the queue never outlives its pass.
+      auto drain_candidates = [&]() {
+        for (uint32_t i = lane_id; i < ((cand_n + 63u) & ~63u); i += 64u) {   // whole waves: bpermute below
+          const uint2 e = cand_q[i < cand_n ? i : 0u];
+          const uint32_t src = (e.y >> 10) & 63u, rel = e.y >> 16;
+          const uint32_t cp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)cpos);
+          uint32_t len, rd;
+          if (FIXED) {
+            len = p.read_len;
+            rd = (uint32_t)r_begin + rel;
+          } else {
+            len = lds_list[rel].y;
+            rd = lds_ridx[rel];
+          }
+          uint32_t hits = i < cand_n ? (e.y >> 2) & 0xFFu : 0u;
+          // only windows that end inside the read, at e >= 9 (quack.c:206-213)
+          const uint32_t n = len - cp;   // > 0: the lane counted something
+          hits &= n >= 8u ? 0xFFu : (1u << n) - 1u;
+          hits &= cp >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cp)) - 1u));
+          const uint64_t stream = ((uint64_t)(e.y & 3u) << 32) | e.x;
+          while (hits) {
+            const uint32_t j = (uint32_t)__builtin_ctz(hits);
+            hits &= hits - 1u;
+            // the window ending at owned position j = bits [2*(7-j), 2*(7-j)+20) of the (complemented) code stream
+            const uint32_t km = ((uint32_t)(stream >> (2u * (7u - j))) & kKmerMask) ^ kKmerMask;
+            const bool in_table = p.bucket_log2 ? bucket_has(lds_buckets, km, p.bucket_mul, p.bucket_log2)
+                                                : ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) != 0;
+            if (in_table) {
+              atomicMin(&p.first_hit[rd], cp + j);
+              break;   // later windows of this chunk are later positions
+            }
+          }
+        }
+        cand_n = 0;
+      };
       auto consume = [&](const u32x3 (&q)[U], const u32x3 (&s)[U], const uint32_t (&nv)[U], const uint32_t (&sk)[U],
-                         const uint32_t (&ridx)[U]) __attribute__((always_inline)) {
+                         const uint32_t (&rl)[U]) __attribute__((always_inline)) {
+      // ADAPT builds run the U reads of a step in two rounds: first the letters of every
+      // read (indicators, counters, codes, the four filter probes), then the quality
+      // histogram and the probes' answers — so that the LDS reads of the probes are
+      // issued ahead of the step's 8*U ds_adds and have long returned when they are
+      // looked at (the kernel issues VALU work back to back on four waves per SIMD and
+      // cannot afford to wait for an LDS round trip per read).
+      uint32_t qwU[U][2], ploU[U], prev16U[U], bytU[U][4];
+      bool liveU[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // bytes past the end of the read -> 0xFF: quality row 127 is discarded
         // at flush time, and 0xFF & 31 matches none of T/C/G.
         const uint32_t n = nv[u];
+        liveU[u] = true;
         // nothing of these reads reaches this tile (ragged batches, long
         // reads): the whole wave moves on.  ADAPT needs every lane's codes, but
         // then no lane has a valid window either.
-        if (!FIXED && __builtin_amdgcn_ballot_w64(n != 0) == 0) continue;
+        if (!FIXED && __builtin_amdgcn_ballot_w64(n != 0) == 0) {
+          liveU[u] = false;
+          continue;
+        }
         if (FAST_FIXED && !ADAPT && n == 0) continue;   // per lane: past the end of the slice (its last step only)
-        const uint2 qa = window8(q[u], sk[u]);
-        const uint2 sa = window8(s[u], sk[u]);
+        const uint2 qa = AL ? make_uint2(q[u].x, q[u].y) : window8(q[u], sk[u]);
+        const uint2 sa = AL ? make_uint2(s[u].x, s[u].y) : window8(s[u], sk[u]);
         // Ragged: bytes past the end of the read -> 0xFF (quality row 127 is
         // discarded at flush time, 0xFF & 31 matches none of T/C/G).  Fixed
         // length: no masks at all — the bytes behind a read's last base belong
@@ -616,7 +687,10 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           continue;
         }
         const bool count_me = !FAST_FIXED || n != 0;   // ragged: every lane (masked bytes take care of themselves)
-        if ((MODE == 0 || MODE == 2) && count_me) {
+        if (ADAPT) {
+          qwU[u][0] = qw[0];
+          qwU[u][1] = qw[1];
+        } else if ((MODE == 0 || MODE == 2) && count_me) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const uint32_t b = __builtin_amdgcn_ubfe(qw[j >> 2], 8 * (j & 3), 7);
@@ -626,9 +700,9 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         if (MODE == 0 || MODE == 3) {
           // letter indicators: the adapter scan needs those of the real bytes
           // (feeder lanes and chunk tails must still yield the real codes; window
-          // validity is enforced by the `hits` masks below); the counters of a
+          // validity is enforced when the candidates are checked); the counters of a
           // ragged batch need every masked byte to read "not equal"
-          uint32_t b0[2] = {0, 0}, b1[2] = {0, 0}, nt[2], nc[2], ng[2];
+          uint32_t nt[2], nc[2], ng[2];
           const uint32_t raw[2] = {sa.x, sa.y};
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
@@ -636,10 +710,6 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
             nt[d] = swar_ne(src, kKeyT);
             nc[d] = swar_ne(src, kKeyC);
             ng[d] = swar_ne(src, kKeyG);
-            if (ADAPT) {   // code bits: low = T or G, high = C or G (at most one letter matches)
-              b0[d] = (nt[d] & ng[d]) ^ 0x01010101u;
-              b1[d] = (nc[d] & ng[d]) ^ 0x01010101u;
-            }
           }
           if (count_me) {
 #pragma unroll
@@ -654,84 +724,63 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           }
           if (!FAST_FIXED) events += 1u;
           if (ADAPT) {
-            // 2-bit codes A0 T1 C2 G3 (quack.c:150) of the 8 owned bases, first
-            // base most significant: byte codes -> 8 bits per dword by multiply
-            uint32_t c8[2];
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-              const uint32_t cb = (b1[d] << 1) + b0[d];
-              c8[d] = (cb * 0x40100401u) >> 24;
-            }
-            const uint32_t own16 = (c8[0] << 8) | c8[1];
+            // COMPLEMENTED 2-bit codes (A and everything else 3, T 2, C 1, G 0) of the 8
+            // owned bases, first base most significant.  The code is LINEAR in the
+            // three indicators, nt + 2 nc + 3 ng - 3, so packing four byte codes
+            // into eight bits (weights 64, 16, 4, 1) is three v_dot4_u32_u8 — no
+            // shifts, no multiplies (v_mul_lo_u32 is quarter rate).
+            constexpr uint32_t kW1 = 0x01041040u, kW2 = 0x02082080u, kW3 = 0x030C30C0u, kBias = 0u - 255u;
+            const uint32_t c80 = __builtin_amdgcn_udot4(ng[0], kW3, __builtin_amdgcn_udot4(nc[0], kW2, __builtin_amdgcn_udot4(nt[0], kW1, kBias, false), false), false);
+            const uint32_t own16 = __builtin_amdgcn_udot4(ng[1], kW3, __builtin_amdgcn_udot4(nc[1], kW2, __builtin_amdgcn_udot4(nt[1], kW1, (c80 << 8) + kBias, false), false), false);
             const uint32_t prev16 = from_prev_lane(own16);   // positions cpos-8 .. cpos-1
-            const uint32_t prev2 = from_prev_lane(prev16);   // its low code: position cpos-9
             const uint32_t plo = (prev16 << 16) | own16;
-            // window ending at owned position j = bits [2*(7-j), 2*(7-j)+20) of
-            // {prev2&3, plo}; the filter is keyed by the window's low 18 bits
-            uint32_t hits = 0;
-#if defined(QK_ABLATE_PROBE_VALU_ONLY)   /* the probes' VALU work without the LDS reads */
+            prev16U[u] = prev16;
+            ploU[u] = plo;
+            // The 9-mer that ends at owned position j is bits [2*(7-j), 2*(7-j)+18)
+            // of plo.  It is the suffix of the window ending at j and the prefix of
+            // the window ending at j+1, and every window has exactly one such 9-mer
+            // ending on an even position: the four probes j = 0,2,4,6 cover the
+            // lane's eight windows.  (The filter holds both 9-mers of every adapter
+            // 10-mer; it sits at LDS byte 0, so the key field is the address.)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bytU[u][m] = lds_abs_u8(__builtin_amdgcn_ubfe(plo, 2 * (7 - 2 * m) + 3, kFusedFilterLog2 - 3));
+          }
+        }
+      }
+      if (ADAPT && MODE == 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!liveU[u]) continue;   // (wave-uniform)
+          const uint32_t n = nv[u];
+          if (!FAST_FIXED || n != 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const int sh = 2 * (7 - j);
-              const uint32_t byte = __builtin_amdgcn_ubfe(plo, sh + 3, kFusedFilterLog2 - 3) * 0x9E3779B1u >> 30;
-              hits |= __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(plo, sh, 3), 1) << j;
+              const uint32_t b = __builtin_amdgcn_ubfe(qwU[u][j >> 2], 8 * (j & 3), 7);
+              lds_add(lds, __umul24(b, row_bytes) + qcol[j & 3], (j >> 2) ? one_hi : one_lo);
             }
-            hits = hits == 0xFFu ? 1u : 0u;
-#elif defined(QK_ABLATE_PROBE_LDS_ONLY)  /* the LDS reads without the bit tests */
-            {
-              uint32_t x = 0;
+          }
+        }
 #pragma unroll
-              for (int j = 0; j < 8; ++j) x += filt8[__builtin_amdgcn_ubfe(plo, 2 * (7 - j) + 3, kFusedFilterLog2 - 3)];
-              hits = x == 0x7F7u ? 1u : 0u;
-            }
-#elif !defined(QK_ABLATE_NO_FILTER)
-            {
-              // all eight reads first (one wait), then the bit tests; the
-              // answers are shifted in from the top (v_alignbit), window 0 first
-              uint32_t byt[8];
+        for (int u = 0; u < U; ++u) {
+          if (!liveU[u]) continue;
+          const uint32_t n = nv[u], plo = ploU[u];
+          uint32_t t9[4];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) byt[j] = lds_abs_u8(__builtin_amdgcn_ubfe(plo, 2 * (7 - j) + 3, kFusedFilterLog2 - 3));
-              uint32_t acc = 0;
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                acc = __builtin_amdgcn_alignbit(byt[j] >> __builtin_amdgcn_ubfe(plo, 2 * (7 - j), 3), acc, 1);
-              hits = acc >> 24;
+          for (int m = 0; m < 4; ++m)   // 0 or ~0
+            t9[m] = (uint32_t)__builtin_amdgcn_sbfe((int)bytU[u][m], __builtin_amdgcn_ubfe(plo, 2 * (7 - 2 * m), 3), 1);
+          // windows j (suffix) and j+1 (prefix) of every 9-mer that passed; lanes that
+          // count nothing (feeders, halo, past the end) have no windows
+          uint32_t hits = (t9[0] & 0x03u) | (t9[1] & 0x0Cu) | (t9[2] & 0x30u) | (t9[3] & 0xC0u);
+          hits = n ? hits : 0u;
+          const uint64_t pushers = __builtin_amdgcn_ballot_w64(hits != 0u);
+          if (pushers) {   // (wave-uniform)
+            const uint32_t prev2 = from_prev_lane(prev16U[u]) & 3u;   // position cpos-9
+            if (hits) {
+              const uint32_t at = cand_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushers, 0u));
+              cand_q[at] = make_uint2(plo, prev2 | (hits << 2) | lane10 | (rl[u] << 16));
             }
-#else
-            hits = (plo == 0x12345u) ? 1u : 0u;   // ablation: keep the codes alive, no LDS probes
-#endif
-            // only windows that end inside the read, at e >= 9 (quack.c:206-213)
-            hits &= (1u << n) - 1u;
-            hits &= win_mask;
-            // Second level, branch-free, for the lane's first candidate: the
-            // first level alone lets ~0.3 % of random windows through (800
-            // adapter 10-mers), i.e. some lane of almost every wave; both
-            // levels together ~2e-5.  Lanes with several candidates go in
-            // regardless (3e-4 of the lanes).
-            bool go;
-            {
-              const uint32_t j1 = (uint32_t)__builtin_ctz(hits | 0x100u) & 7u;
-              const uint32_t w1 = (uint32_t)(((((uint64_t)(prev2 & 3u)) << 32) | plo) >> (2u * (7u - j1))) & 0xFFFFFu;
-              const uint32_t b2 = lds_abs_u8((1u << kFusedFilterLog2) / 8u + (w1 >> 6));
-              const bool pass2 = ((b2 >> ((w1 >> 3) & 7u)) & 1u) != 0;
-              go = hits != 0 && (pass2 || (hits & (hits - 1u)) != 0);
-            }
-            if (go) {
-              uint32_t best = kNoHit;
-              while (hits) {
-                const int j = __builtin_ctz(hits);
-                hits &= hits - 1u;
-                const uint32_t km = (uint32_t)(((((uint64_t)(prev2 & 3u)) << 32) | plo) >> (2 * (7 - j))) & 0xFFFFFu;
-                const bool in_table = p.bucket_log2 ? bucket_has(lds_buckets, km, p.bucket_mul, p.bucket_log2)
-                                                    : ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) != 0;
-                if (in_table) {
-                  best = cpos + (uint32_t)j;
-                  break;
-                }
-              }
-              if (best != kNoHit)
-                atomicMin(&p.first_hit[ridx[u]], best);
-            }
+            cand_n += (uint32_t)__builtin_popcountll(pushers);
+            if (cand_n > kCandCap - 64u) drain_candidates();
           }
         }
       }
@@ -744,27 +793,28 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
         // PD register sets: the loads of the next PD-1 steps are in flight
         // while one step is consumed
         u32x3 q[PD][U], s[PD][U];
-        uint32_t nv[PD][U], sk[PD][U], ridx[PD][U];
+        uint32_t nv[PD][U], sk[PD][U], rl[PD][U];
 #pragma unroll
-        for (int d = 0; d < PD - 1; ++d) issue((uint32_t)d * RW * U, q[d], s[d], nv[d], sk[d], ridx[d]);
+        for (int d = 0; d < PD - 1; ++d) issue((uint32_t)d * RW * U, q[d], s[d], nv[d], sk[d], rl[d]);
         for (uint32_t it = 0; it < n_list; it += (uint32_t)PD * RW * U) {
 #pragma unroll
           for (int d = 0; d < PD; ++d) {
             const int nx = (d + PD - 1) % PD;
-            issue(it + (uint32_t)(d + PD - 1) * RW * U, q[nx], s[nx], nv[nx], sk[nx], ridx[nx]);
-            if (d == 0 || it + (uint32_t)d * RW * U < n_list) consume(q[d], s[d], nv[d], sk[d], ridx[d]);
+            issue(it + (uint32_t)(d + PD - 1) * RW * U, q[nx], s[nx], nv[nx], sk[nx], rl[nx]);
+            if (d == 0 || it + (uint32_t)d * RW * U < n_list) consume(q[d], s[d], nv[d], sk[d], rl[d]);
           }
         }
       } else {
         if (!FIXED) load_desc(0u);
         for (uint32_t it = 0; it < n_list; it += RW * U) {
           u32x3 q[U], s[U];
-          uint32_t nv[U], sk[U], ridx[U];
-          issue(it, q, s, nv, sk, ridx);
+          uint32_t nv[U], sk[U], rl[U];
+          issue(it, q, s, nv, sk, rl);
           if (!FIXED) load_desc(it + RW * U);
-          consume(q, s, nv, sk, ridx);
+          consume(q, s, nv, sk, rl);
         }
       }
+      if (ADAPT && cand_n) drain_candidates();   // the entries refer to this pass's read list
     }
     if (MODE == 0 || MODE == 3) spill();
     return slice_reads;

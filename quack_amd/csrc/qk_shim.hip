@@ -9,6 +9,7 @@
 #include "quack_hip.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -187,7 +188,8 @@ constexpr unsigned kQueueTiles = 1u << 17;  // counters per launch: reads of up 
 // (measured on 300 bp: two 152-wide tiles 1.78 ms, one 304-wide tile 1.10 ms).
 // Longer reads get tiles of <= 512 positions.  The grid is sized to residency:
 // workgroups per CU = what the LDS admits (at most 2 of 1024 threads).
-int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, bool gapped, bool aligned, Plan *pl) {
+int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, bool gapped, bool aligned, Plan *pl,
+              bool base_aligned4 = true) {
   const uint32_t T = (uint32_t)a->threads;
   pl->fused_adapters = a->adapters && !getenv("QUACK_HIP_UNFUSED_ADAPTERS");
   // reads per lane and step / software pipeline depth.  Measured (10M x 150,
@@ -202,7 +204,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   const uint32_t U = (uint32_t)pl->unroll;
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
   uint32_t single_cap = 576u;
-  while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, a->adapters, a->adapters ? a->bucket_log2 : 0, ragged) > 160 * 1024)
+  while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, a->adapters, 0, ragged) > 160 * 1024)
     single_cap -= 32u;
   uint32_t cap = a->tile > 0 ? std::max<uint32_t>(8, (uint32_t)a->tile / 8 * 8) : single_cap;
   cap = std::min(cap, single_cap);
@@ -225,12 +227,19 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
     tile_pos = cap / 128 * 128;
     n_tiles = (max_len + tile_pos - 1) / tile_pos;
   }
+  // fixed-length reads of a multiple of 4 bases: every chunk is dword aligned
+  // (the batch base is: hipMalloc / pinned slots; submit_device checks it)
+  if (!ragged && (max_len & 3u) == 0 && base_aligned4 && T == 1024 && !a->unroll && !a->pipe &&
+      !getenv("QUACK_HIP_NO_ALIGN4"))
+    pl->aligned = true;
   pl->n_tiles = n_tiles;
   pl->tile_pos = tile_pos;
   pl->ch = tile_pos / 8;
   pl->halo = (pl->fused_adapters && n_tiles > 1) ? 2u : 0u;   // lanes covering the 16 positions before a tile
   pl->rw = (pl->fused_adapters ? T / 64 * 62 : T) / (pl->ch + pl->halo);
   const uint64_t step = (uint64_t)pl->rw * U;
+  // the exact table next to the histogram, if it fits (it never narrows a tile: without it
+  // the queued candidates are checked against the global table)
   pl->bucket_log2 = pl->fused_adapters ? a->bucket_log2 : 0;
   if (pl->bucket_log2 && qk::hist_lds_bytes(pl->ch, true, pl->bucket_log2, ragged) > 160 * 1024) pl->bucket_log2 = 0;
   // ragged: reads staged per pass.  A pass should hold many steps (36 bp reads: 816 per
@@ -294,6 +303,10 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
     // only built for the planner's own choice (make_plan sets `aligned` for nothing else)
     if constexpr (T == 1024 && U == 4 && PD == 1)
       k = adapt ? qk::hist_kernel<T, U, false, 0, true, PD, true> : qk::hist_kernel<T, U, false, 0, false, PD, true>;
+  }
+  if (aligned && fixed && mode == 0) {
+    if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 4))
+      k = adapt ? qk::hist_kernel<T, U, true, 0, true, PD, true> : qk::hist_kernel<T, U, true, 0, false, PD, true>;
   }
   if (k) {
   } else if (adapt) {
@@ -385,7 +398,8 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   }
   Plan pl;
   if (d_len && total_bytes > 0x7FFFFFF0ull) return fail(QK_EINVAL, "a gapped batch must stay below 2 GiB");
-  rc = make_plan(a, n_reads, max_len, d_off != nullptr, d_len != nullptr, d_len && (flags & QK_BATCH_ALIGNED128), &pl);
+  rc = make_plan(a, n_reads, max_len, d_off != nullptr, d_len != nullptr, d_len && (flags & QK_BATCH_ALIGNED128), &pl,
+                 (((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) == 0);
   if (rc) return rc;
   if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));
   TimedLaunch tl{};
@@ -584,12 +598,36 @@ const RcclApi &rccl_api() {
   return g_rccl;
 }
 
+// RCCL writes its version banner and NCCL_DEBUG output to STDOUT — which for
+// quack is the SVG document (measured: "RCCL version ..." in front of <svg> with
+// QUACK_DEVICES=0,1).  While the RCCL section runs (under g_rccl_mu), file
+// descriptor 1 points at stderr; stdio buffers are flushed on both sides of
+// the switch so that nothing crosses over.
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0 && dup2(2, 1) < 0) {
+      close(saved);
+      saved = -1;
+    }
+  }
+  ~StdoutToStderr() {
+    if (saved < 0) return;
+    fflush(stdout);
+    (void)dup2(saved, 1);
+    close(saved);
+  }
+};
+
 // One all-reduce(SUM, u64) of `words` table words over the accumulators `who`
 // (distinct devices).  Caller holds nothing; this takes g_rccl_mu.
 int rccl_sum_tables(qk_accum **who, int n, size_t words) {
   const RcclApi &api = rccl_api();
   if (!api.ok) return fail(QK_ERCCL, "%s", api.why);
   std::lock_guard<std::mutex> lock(g_rccl_mu);
+  StdoutToStderr quiet;   // RCCL logs to stdout; the host's stdout is the SVG
   std::vector<int> devs(n);
   for (int i = 0; i < n; ++i) devs[i] = who[i]->device;
   auto it = g_rccl_comms.find(devs);
@@ -714,7 +752,7 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
           break;
         }
       } else {
-        a->bucket_log2 = 0;   // huge adapter set: filter hits consult the global bitset
+        a->bucket_log2 = 0;   // huge adapter set: the candidates consult the global bitset
       }
     }
     if (hipMalloc((void **)&a->d_status, sizeof(uint32_t)) != hipSuccess ||

@@ -46,7 +46,8 @@ def test_plans_fit_the_hardware(ragged, adapters):
         assert p["dynamic"] == (p["n_tiles"] > 1), ctx
         assert p["n_blocks"] >= 1 and (p["dynamic"] or p["n_blocks"] == p["n_slices"]), ctx
         assert (p["unroll"], p["pipe"]) == ((4, 1) if ragged else ((4, 2) if adapters else (1, 2))), ctx
-        assert not p["aligned"]
+        # fixed-length reads of a multiple of 4 bases take the dword-aligned variant (one dwordx2 per chunk)
+        assert p["aligned"] == (not ragged and max_len % 4 == 0), ctx
 
 
 def test_cache_line_plans():

@@ -143,6 +143,11 @@ static void run_var(const char *name, const uint8_t *a, const uint8_t *b, size_t
   }
 }
 
+static int base_code(uint8_t c) {
+  unsigned k = c & 31u;
+  return k == 20 ? 1 : k == 3 ? 2 : k == 7 ? 3 : 0;
+}
+
 static inline uint64_t splitmix(uint64_t &s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -150,10 +155,6 @@ static inline uint64_t splitmix(uint64_t &s) {
   return z ^ (z >> 31);
 }
 
-static int base_code(uint8_t c) {
-  unsigned k = c & 31u;
-  return k == 20 ? 1 : k == 3 ? 2 : k == 7 ? 3 : 0;
-}
 
 int main(int argc, char **argv) {
   uint64_t n_reads = argc > 1 ? strtoull(argv[1], 0, 10) : 10000000ull;
@@ -192,9 +193,34 @@ int main(int argc, char **argv) {
   std::vector<uint32_t> bits;
   if (adapters) {
     bits.assign(QK_KMER_TABLE_WORDS, 0);
-    for (int i = 0; i < 333; ++i) {
-      uint32_t km = (uint32_t)(splitmix(seed) & 0xFFFFF);
-      bits[km >> 5] |= 1u << (km & 31);
+    const double splice = getenv("KB_SPLICE") ? atof(getenv("KB_SPLICE")) : 0.0;
+    if (splice > 0 && !ragged) {
+      // config 3's shape: 24 adapters of 30-60 nt (read_adapters rule: the first 10-mer of a record is not
+      // inserted, quack.c:164-172), a fraction of the reads gets one at a uniform offset, cut at the read end
+      std::vector<std::vector<uint8_t>> ads(24);
+      for (auto &a : ads) {
+        a.resize(30 + splitmix(seed) % 31);
+        for (auto &c : a) c = (uint8_t)B[splitmix(seed) & 3];
+        uint32_t idx = 0;
+        for (size_t i = 0; i < a.size(); ++i) {
+          idx = ((idx << 2) + (uint32_t)base_code(a[i])) & 0xFFFFF;
+          if (i >= 10) bits[idx >> 5] |= 1u << (idx & 31);
+        }
+      }
+      uint64_t n_spliced = 0;
+      for (uint64_t r = 0; r < n_reads; ++r) {
+        if ((double)(splitmix(seed) >> 11) * (1.0 / 9007199254740992.0) >= splice) continue;
+        const auto &a = ads[splitmix(seed) % ads.size()];
+        const uint32_t at = (uint32_t)(splitmix(seed) % read_len);
+        for (uint32_t i = 0; i < a.size() && at + i < read_len; ++i) seq[off[r] + at + i] = a[i];
+        ++n_spliced;
+      }
+      printf("spliced an adapter into %llu reads\n", (unsigned long long)n_spliced);
+    } else {
+      for (int i = 0; i < 333; ++i) {
+        uint32_t km = (uint32_t)(splitmix(seed) & 0xFFFFF);
+        bits[km >> 5] |= 1u << (km & 31);
+      }
     }
   }
   printf("batch: %llu reads, %llu bases, max_len %u, ragged=%d adapters=%d\n",
