@@ -62,8 +62,11 @@ WORKLOADS = {
     "cfg4": dict(n=6_250_000, L=150, ragged=None, adapters=False, paired=True,
                  label="paired 2x50M 150 bp sharded over 8 GPUs: per-GPU share 2 x 6.25M reads (configs[3])"),
     # trimmed Illumina: 150 bp reads, most of them full length, the rest cut back to 120..149
-    "trimmed": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7,
-                    label="10M-read synthetic trimmed 150 bp FASTQ (70% full length, rest 120-149), ragged"),
+    "trimmed": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7, stride=152,
+                    label="10M-read synthetic trimmed 150 bp FASTQ (70% full length, rest 120-149), fixed stride 152 + "
+                          "per-read lengths as the host feed lays such reads out"),
+    "trimmedpacked": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7,
+                          label="10M-read synthetic trimmed 150 bp FASTQ (70% full length, rest 120-149), packed ragged"),
 }
 
 
@@ -131,7 +134,11 @@ def make_batch(torch, np, w, seed, device, quality="uniform", q_hi_override=None
         if w.get("full"):
             lens[rng.random(w["n"]) < w["full"]] = w["ragged"][1]
         d_len = None
-        if w.get("aligned"):
+        if w.get("stride"):
+            extent = w["n"] * w["stride"]
+            d_off = None
+            d_len = torch.from_numpy(lens.astype(np.int32)).to(device)
+        elif w.get("aligned"):
             starts = np.concatenate([[0], np.cumsum((lens + 127) // 128 * 128)]).astype(np.int64)
             extent = int(starts[-2] + lens[-1])
             d_off = torch.from_numpy(starts[:-1].copy()).to(device)
@@ -177,7 +184,7 @@ def make_batch(torch, np, w, seed, device, quality="uniform", q_hi_override=None
             seq[(pick * L + at + j)[ok]] = tab[which[ok], j]
         spliced = int(len(pick))
     return dict(seq=seq, qual=qual, d_off=d_off, d_len=d_len, total=total, max_len=max_len, extent=extent,
-                n=w["n"], spliced=spliced)
+                n=w["n"], spliced=spliced, stride=w.get("stride") if w["ragged"] else None)
 
 
 def synthetic_adapter_bits(np, seed=3):
@@ -196,12 +203,22 @@ def synthetic_adapter_bits(np, seed=3):
 
 
 def alg_bytes_of(b):
+    if b.get("stride"):
+        return 2.0 * b["total"] + 4.0 * b["n"]          # strided: 4 B/read of lengths
     return 2.0 * b["total"] + ((12.0 if b["d_len"] is not None else 8.0) * b["n"] if b["d_off"] is not None else 0.0)
 
 
 def host_sample(np, b, w, budget_bases):
     """the first reads of the GPU batch, packed, on the host: (seq, qual, offsets or None, reads, bases)"""
     n = b["n"]
+    if b.get("stride"):   # strided on the device: the oracle takes the same reads packed
+        st = b["stride"]
+        lens = b["d_len"].cpu().numpy().astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        m = int(min(n, max(1, np.searchsorted(off, budget_bases))))
+        gs, gq = b["seq"][:m * st].cpu().numpy().reshape(m, st), b["qual"][:m * st].cpu().numpy().reshape(m, st)
+        keep = np.arange(st)[None, :] < lens[:m, None]
+        return gs[keep], gq[keep], off[:m + 1], m, int(off[m])
     if b["d_off"] is None:
         m = min(n, max(1, budget_bases // w["L"]))
         return b["seq"][:m * w["L"]].cpu().numpy(), b["qual"][:m * w["L"]].cpu().numpy(), None, m, m * w["L"]
@@ -278,7 +295,9 @@ def time_workload(torch, quack_amd, w, b, local, bits, steps, warmup, stream=Non
     acc = quack_amd.Accumulator(local, bits, max_len_hint=b["max_len"])
 
     def step():
-        if b["d_len"] is not None:
+        if b.get("stride"):
+            acc.submit_device_strided(b["seq"], b["qual"], b["d_len"], b["n"], b["stride"], b["max_len"], stream=stream)
+        elif b["d_len"] is not None:
             acc.submit_device_gapped(b["seq"], b["qual"], b["d_off"], b["d_len"], b["n"], b["extent"], b["max_len"],
                                      aligned=True, stream=stream)
         else:
@@ -372,7 +391,9 @@ def main():
     shared_stream = side.cuda_stream if side is not None else None
 
     def step():
-        if d_len is not None:
+        if b.get("stride"):
+            acc.submit_device_strided(seq, qual, d_len, n, b["stride"], max_len, stream=shared_stream)
+        elif d_len is not None:
             acc.submit_device_gapped(seq, qual, d_off, d_len, n, extent, max_len, aligned=True, stream=shared_stream)
         else:
             acc.submit_device(seq, qual, d_off, n, total, max_len, stream=shared_stream)
@@ -431,7 +452,7 @@ def main():
     sd = acc.finish()
     # after the all-reduce every rank holds the sum over ranks (equal batch sizes for fixed-length workloads)
     got = int(sd.bases[:, 91:95].sum())
-    if d_off is None:
+    if d_off is None and not b.get("stride"):
         expect = (args.warmup + args.steps) * total * world
         if got != expect:
             raise SystemExit("counter check failed: content sum %d != %d" % (got, expect))

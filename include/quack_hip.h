@@ -138,6 +138,24 @@ int qk_accum_submit_device_gapped(qk_accum *acc, const void *d_seq, const void *
 int qk_accum_slot_lengths(qk_accum *acc, uint32_t **lengths);
 int qk_accum_commit_gapped(qk_accum *acc, uint64_t n_reads, uint64_t extent_bytes, uint32_t flags);
 
+/* ---- strided batches: fixed stride, per-read lengths -------------------------
+ * Read r occupies bytes [r * stride, r * stride + lengths[r]) of seq / qual;
+ * stride is a multiple of 4 and >= every length; the bytes behind a read's
+ * last base are never counted.  This is the form for short reads that are
+ * *nearly* all one length (adapter/quality-trimmed Illumina runs): the
+ * kernels keep the address arithmetic and the software-pipelined loop of a
+ * fixed-length batch and mask the tails (a packed ragged batch of the same
+ * reads runs ~20 % slower).  The host tokenizer switches to it by itself
+ * (quack_amd/host/pipeline.c).  Algorithmic traffic: 2 B/base + 4 B/read.
+ * Pinned-slot form: lengths go into the array of qk_accum_slot_lengths. */
+int qk_accum_submit_device_strided(qk_accum *acc, const void *d_seq, const void *d_qual,
+                                   const void *d_lengths /* u32[n_reads] */, uint64_t n_reads,
+                                   uint32_t stride, uint32_t max_len, void *hip_stream);
+int qk_accum_commit_strided(qk_accum *acc, uint64_t n_reads, uint32_t stride);
+/* copying feed from caller-owned host memory (any size; split internally) */
+int qk_accum_submit_strided(qk_accum *acc, const uint8_t *seq, const uint8_t *qual,
+                            const uint32_t *lengths, uint32_t stride, uint64_t n_reads);
+
 /* Wait for everything enqueued so far. */
 int qk_accum_sync(qk_accum *acc);
 

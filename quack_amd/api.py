@@ -158,6 +158,16 @@ class Accumulator:
         _check(self._L.qk_accum_submit_fixed(self._h, seq.ctypes.data, qual.ctypes.data, read_len,
                                              len(seq) // read_len))
 
+    def submit_strided(self, seq, qual, lengths, stride):
+        """fixed stride, own lengths (qk_accum_submit_strided): read r is seq[r*stride : r*stride + lengths[r]]"""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        if stride <= 0 or len(seq) != len(lengths) * stride or len(seq) != len(qual):
+            raise ValueError("inconsistent strided batch")
+        _check(self._L.qk_accum_submit_strided(self._h, seq.ctypes.data, qual.ctypes.data, lengths.ctypes.data,
+                                               stride, len(lengths)))
+
     def submit_gapped(self, seq, qual, starts, lengths, aligned=False):
         """one gapped batch through a pinned slot (qk_accum_acquire / slot_lengths /
         commit_gapped): read r is seq[starts[r] : starts[r] + lengths[r]]"""
@@ -192,6 +202,12 @@ class Accumulator:
         _check(self._L.qk_accum_submit_device_gapped(
             self._h, d_seq.data_ptr(), d_qual.data_ptr(), d_starts.data_ptr(), d_lengths.data_ptr(),
             n_reads, extent_bytes, max_len, QK_BATCH_ALIGNED128 if aligned else 0, stream))
+
+    def submit_device_strided(self, d_seq, d_qual, d_lengths, n_reads, stride, max_len, stream=None):
+        """read r at [r*stride, r*stride + lengths[r]); lengths: int32/uint32[n] device tensor; stride % 4 == 0;
+        see qk_accum_submit_device_strided"""
+        _check(self._L.qk_accum_submit_device_strided(
+            self._h, d_seq.data_ptr(), d_qual.data_ptr(), d_lengths.data_ptr(), n_reads, stride, max_len, stream))
 
     def submit_device(self, d_seq, d_qual, d_offsets, n_reads, total_bytes, max_len, stream=None):
         """d_* expose data_ptr(); buffers need QK_TAIL_SLACK readable bytes

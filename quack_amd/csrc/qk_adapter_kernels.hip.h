@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kScanThreads) void adapter_scan_kernel(const HistPa
     uint32_t len;
     if (FIXED) {
       start = r * p.read_len;
-      len = p.read_len;
+      len = p.lengths ? p.lengths[r] : p.read_len;   // (strided batch: fixed stride, own lengths)
     } else {
       start = p.offsets[r];
       len = p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - start);
@@ -130,7 +130,7 @@ inline int launch_adapter_count(const HistParams &hp, int n_cu, hipStream_t st) 
   if (hp.n_reads == 0) return 0;
   uint64_t cblocks = (hp.n_reads + kCountThreads - 1) / kCountThreads;
   if (cblocks > (uint64_t)n_cu * 4) cblocks = (uint64_t)n_cu * 4;
-  if (hp.offsets == nullptr)
+  if (hp.offsets == nullptr && hp.lengths == nullptr)
     hipLaunchKernelGGL(adapter_count_kernel<true>, dim3((unsigned)cblocks), dim3(kCountThreads), 0, st, hp);
   else
     hipLaunchKernelGGL(adapter_count_kernel<false>, dim3((unsigned)cblocks), dim3(kCountThreads), 0, st, hp);

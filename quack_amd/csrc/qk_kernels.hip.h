@@ -231,8 +231,19 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 // AL, fixed length: read_len is a multiple of 4 (36, 76, 100, 300 ...), so every
 // chunk starts on a dword: one global_load_dwordx2, no 12-byte window, no
 // v_alignbyte.
-template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false>
-__global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
+// SV (fixed stride, variable length; FIXED and AL too): read r occupies
+// [r * stride, r * stride + lengths[r]) with stride = p.read_len a multiple of 4 —
+// the form the host feed gives trimmed short reads (most of them full length): the
+// addresses, the pipelined step loop and the dword loads of a fixed-length batch,
+// plus the tail masks of a ragged one.  The length of a read travels with its
+// loads (one more dword in flight per read); length_count comes from
+// ragged_length_kernel.
+// (SV builds are held to 64 VGPRs: with the tail masks the loop is VALU-heavier than
+// the fixed-length one and gains from two workgroups per CU, 0.61 -> 0.53 ms per 10M
+// trimmed 150 bp reads; the plain fixed-length kernel is faster with one)
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false>
+__global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
+  static_assert(!SV || (FIXED && AL), "strided batches are a variant of the dword-aligned fixed-length path");
   extern __shared__ uint32_t lds_raw[];
   // ADAPT: the window filter sits first, so that the probes' LDS addresses are
   // "field + constant" (no per-probe add of a layout-dependent base)
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
   // go one step further: the tail masks are per-lane constants (fm0/fm1), lanes past
   // the end of the slice sit out under the exec mask and count their own
   // events (steps_v), and no per-event valid counter is needed at all.
-  constexpr bool FAST_FIXED = FIXED;
+  constexpr bool FAST_FIXED = FIXED && !SV;
   uint32_t events = 0, steps_v = 0, fm0 = 0xFFFFFFFFu, fm1 = 0xFFFFFFFFu;
 
   auto spill = [&]() {
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
       if (g) atomicAdd(row0 + 3u * TL, (unsigned long long)g);
     }
     if (tile == 0) {
-      if (FIXED) {
+      if (FAST_FIXED) {
         if (tid == 0 && fixed_reads != 0) {
           const unsigned long long n = fixed_reads;
           if (p.read_len != 0)
@@ -575,6 +586,8 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           uint32_t n_raw = (in_list && len > cpos) ? len - cpos : 0u;
           n_raw = n_raw > 8u ? 8u : n_raw;
           nv[u] = lane_on ? n_raw : 0u;
+          // strided: the read's own length, in flight together with its bytes (consume turns it into n)
+          if (SV) nv[u] = in_list ? p.lengths[(size_t)r_begin + rel] : 0u;
           off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
           sk[u] = AL ? 0u : (off & 3u);
           off &= (AL && !FIXED) ? ~7u : ~3u;
@@ -613,8 +626,8 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
           const uint32_t cp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)cpos);
           uint32_t len, rd;
           if (FIXED) {
-            len = p.read_len;
             rd = (uint32_t)r_begin + rel;
+            len = SV ? p.lengths[rd] : p.read_len;
           } else {
             len = lds_list[rel].y;
             rd = lds_ridx[rel];
@@ -648,13 +661,18 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
       // issued ahead of the step's 8*U ds_adds and have long returned when they are
       // looked at (the kernel issues VALU work back to back on four waves per SIMD and
       // cannot afford to wait for an LDS round trip per read).
-      uint32_t qwU[U][2], ploU[U], prev16U[U], bytU[U][4];
+      uint32_t qwU[U][2], ploU[U], prev16U[U], bytU[U][4], nU[U];
       bool liveU[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // bytes past the end of the read -> 0xFF: quality row 127 is discarded
         // at flush time, and 0xFF & 31 matches none of T/C/G.
-        const uint32_t n = nv[u];
+        uint32_t n = nv[u];
+        if (SV) {   // nv[u] is the length of the read
+          n = (lane_on && nv[u] > cpos) ? nv[u] - cpos : 0u;
+          n = n > 8u ? 8u : n;
+        }
+        nU[u] = n;
         liveU[u] = true;
         // nothing of these reads reaches this tile (ragged batches, long
         // reads): the whole wave moves on.  ADAPT needs every lane's codes, but
@@ -751,7 +769,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (!liveU[u]) continue;   // (wave-uniform)
-          const uint32_t n = nv[u];
+          const uint32_t n = nU[u];
           if (!FAST_FIXED || n != 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -763,7 +781,7 @@ __global__ __launch_bounds__(T, QK_MIN_WAVES_PER_SIMD) void hist_kernel(const Hi
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (!liveU[u]) continue;
-          const uint32_t n = nv[u], plo = ploU[u];
+          const uint32_t n = nU[u], plo = ploU[u];
           uint32_t t9[4];
 #pragma unroll
           for (int m = 0; m < 4; ++m)   // 0 or ~0
@@ -1003,31 +1021,124 @@ __global__ __launch_bounds__(kReachThreads) void reach_scatter_kernel(const Hist
   }
 }
 
+// cnt[key] += 1 for every lane with `valid`, adding lanes that hold the same key up
+// first: real batches are dominated by one or two lengths, and 64 lanes adding to
+// one LDS address serialise (10M reads, 70 % of one length: 53 us -> 12 us)
+__device__ __forceinline__ void wave_count_lds(uint32_t *cnt, uint32_t key, bool valid) {
+  uint64_t left = __builtin_amdgcn_ballot_w64(valid);
+  const uint32_t lane = threadIdx.x & 63u;
+  for (int k = 0; k < 3 && left; ++k) {
+    const uint32_t leader = (uint32_t)__builtin_ctzll(left);
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)leader);
+    const uint64_t same = __builtin_amdgcn_ballot_w64(valid && key == v);
+    if (lane == leader) atomicAdd(&cnt[v], (uint32_t)__builtin_popcountll(same));
+    if (key == v) valid = false;
+    left &= ~same;
+  }
+  if (valid) atomicAdd(&cnt[key], 1u);
+}
+
 // length_count and the kmers==NULL count (quack.c:215-219) of a ragged batch
 // that spans several tiles.  Inside hist_kernel only lengths below the tile
 // width have an LDS counter; longer ones would be one global atomic per read —
 // 5M reads of ~600 bases on 20 addresses: 11.3 ms instead of 1.3.  Here every
 // block privatises the first 8192 lengths in LDS (longer reads come in few
 // copies per length) and flushes what is non-zero.
-__global__ __launch_bounds__(256) void ragged_length_kernel(const HistParams p) {
+// (1024 threads per block and one block per CU: every block ends with one global atomic per
+// length it met, and same-address atomics serialise at ~15 ns — 2048 blocks cost 30 us there)
+constexpr int kLenThreads = 1024;
+__global__ __launch_bounds__(kLenThreads) void ragged_length_kernel(const HistParams p) {
   __shared__ uint32_t cnt[kLenLds];
   __shared__ uint32_t gt10;
-  for (uint32_t i = threadIdx.x; i < kLenLds; i += 256) cnt[i] = 0;
+  for (uint32_t i = threadIdx.x; i < kLenLds; i += kLenThreads) cnt[i] = 0;
   if (threadIdx.x == 0) gt10 = 0;
   __syncthreads();
   uint32_t mine = 0;
-  for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < p.n_reads; r += (uint64_t)gridDim.x * 256) {
-    const uint32_t len = p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]);
-    mine += len > 10u ? 1u : 0u;
-    if (len == 0) continue;
+  auto one = [&](uint32_t len, bool in) {
+    mine += (in && len > 10u) ? 1u : 0u;
     const uint32_t lp = len - 1u;
-    if (lp < kLenLds) atomicAdd(&cnt[lp], 1u);
-    else atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + lp], 1ull);
+    wave_count_lds(cnt, lp, in && len != 0 && lp < kLenLds);
+    if (in && len != 0 && lp >= kLenLds) atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + lp], 1ull);
+  };
+  // (whole waves per round: wave_count_lds uses ballots)
+  if (p.lengths && (reinterpret_cast<uintptr_t>(p.lengths) & 15u) == 0) {
+    // four lengths per lane and load: one dword per lane in flight moves 40 MB of lengths
+    // (10M reads) at a twentieth of the memory rate (measured 85 us)
+    const uint4 *l4 = reinterpret_cast<const uint4 *>(p.lengths);
+    const uint64_t groups = (p.n_reads + 3) / 4;
+    for (uint64_t g0 = (uint64_t)blockIdx.x * kLenThreads; g0 < groups; g0 += (uint64_t)gridDim.x * kLenThreads) {
+      const uint64_t g = g0 + threadIdx.x;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g * 4 + 3 < p.n_reads) {
+        v = l4[g];
+      } else if (g < groups) {
+        const uint32_t *tail = p.lengths + g * 4;
+        const uint64_t left = p.n_reads - g * 4;
+        v.x = tail[0];
+        if (left > 1) v.y = tail[1];
+        if (left > 2) v.z = tail[2];
+      }
+      one(v.x, g * 4 < p.n_reads);
+      one(v.y, g * 4 + 1 < p.n_reads);
+      one(v.z, g * 4 + 2 < p.n_reads);
+      one(v.w, g * 4 + 3 < p.n_reads);
+    }
+  } else {
+    for (uint64_t r0 = (uint64_t)blockIdx.x * kLenThreads; r0 < p.n_reads; r0 += (uint64_t)gridDim.x * kLenThreads) {
+      const uint64_t r = r0 + threadIdx.x;
+      const bool in = r < p.n_reads;
+      one(!in ? 0u : (p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r])), in);
+    }
   }
   if (mine) atomicAdd(&gt10, mine);
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < kLenLds && i < p.table_len; i += 256)
+  for (uint32_t i = threadIdx.x; i < kLenLds && i < p.table_len; i += kLenThreads)
     if (cnt[i]) atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + i], (unsigned long long)cnt[i]);
+  if (threadIdx.x == 0 && p.no_adapters && gt10)
+    atomicAdd(&p.table[(uint64_t)kRowKmer * p.table_len + 10u], (unsigned long long)gt10);
+}
+
+// The same for batches whose reads are at most kShortLen long (strided batches of
+// trimmed short reads: millions of reads on a few dozen lengths, most of them on
+// ONE).  Counters [length][32]: a lane adds into column lane % 32, so the LDS
+// atomics of a wave never share a bank, let alone an address (two lanes at
+// most) — no ballots, no serialisation: 10M reads 48 us -> ~8 us.
+constexpr uint32_t kShortLen = 512;
+__global__ __launch_bounds__(kLenThreads) void short_length_kernel(const HistParams p) {
+  __shared__ uint32_t cnt[kShortLen * 32u];
+  __shared__ uint32_t gt10;
+  for (uint32_t i = threadIdx.x; i < kShortLen * 32u; i += kLenThreads) cnt[i] = 0;
+  if (threadIdx.x == 0) gt10 = 0;
+  __syncthreads();
+  const uint32_t col = threadIdx.x & 31u;
+  uint32_t mine = 0;
+  auto one = [&](uint32_t len) {
+    mine += len > 10u ? 1u : 0u;
+    if (len != 0 && len <= kShortLen) atomicAdd(&cnt[(len - 1u) * 32u + col], 1u);
+    else if (len != 0) atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + len - 1u], 1ull);   // (not expected)
+  };
+  if ((reinterpret_cast<uintptr_t>(p.lengths) & 15u) == 0) {
+    const uint4 *l4 = reinterpret_cast<const uint4 *>(p.lengths);
+    const uint64_t groups = p.n_reads / 4;
+    for (uint64_t g = (uint64_t)blockIdx.x * kLenThreads + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * kLenThreads) {
+      const uint4 v = l4[g];
+      one(v.x);
+      one(v.y);
+      one(v.z);
+      one(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (p.n_reads & 3u)) one(p.lengths[groups * 4 + threadIdx.x]);
+  } else {
+    for (uint64_t r = (uint64_t)blockIdx.x * kLenThreads + threadIdx.x; r < p.n_reads; r += (uint64_t)gridDim.x * kLenThreads)
+      one(p.lengths[r]);
+  }
+  if (mine) atomicAdd(&gt10, mine);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kShortLen && i < p.table_len; i += kLenThreads) {
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < 32u; ++k) c += cnt[i * 32u + ((k + i) & 31u)];   // (staggered: no bank conflicts)
+    if (c) atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + i], (unsigned long long)c);
+  }
   if (threadIdx.x == 0 && p.no_adapters && gt10)
     atomicAdd(&p.table[(uint64_t)kRowKmer * p.table_len + 10u], (unsigned long long)gt10);
 }

@@ -189,18 +189,19 @@ constexpr unsigned kQueueTiles = 1u << 17;  // counters per launch: reads of up 
 // Longer reads get tiles of <= 512 positions.  The grid is sized to residency:
 // workgroups per CU = what the LDS admits (at most 2 of 1024 threads).
 int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, bool gapped, bool aligned, Plan *pl,
-              bool base_aligned4 = true) {
+              bool base_aligned4 = true, bool strided = false) {
   const uint32_t T = (uint32_t)a->threads;
   pl->fused_adapters = a->adapters && !getenv("QUACK_HIP_UNFUSED_ADAPTERS");
   // reads per lane and step / software pipeline depth.  Measured (10M x 150,
   // 5M x 300 + adapters, 1-20 kb ragged; kbench): fixed-length batches like
   // the next step's loads in flight while one is consumed — with one read per
-  // step when there is no adapter scan (70 VGPRs, 0.546 -> 0.527 ms), four
-  // with it (0.915 -> 0.878 ms); the ragged path (LDS-staged descriptors) is
+  // step when there is no adapter scan (70 VGPRs, 0.546 -> 0.527 ms), two
+  // with it (round 2, 10M x 300 spliced: (4,2) 1.542, (2,2) 1.495, (1,2) 1.495,
+  // (4,1) 1.508, (1,1) 1.771 ms); the ragged path (LDS-staged descriptors) is
   // best unpipelined.
   const bool want_pipe = a->pipe > 0 ? a->pipe > 1 : (a->unroll <= 0 && !ragged && T == 1024);
   pl->pipe = a->pipe > 0 ? a->pipe : (want_pipe ? 2 : 1);
-  pl->unroll = a->unroll > 0 ? a->unroll : ((want_pipe && !ragged && !pl->fused_adapters) ? 1 : 4);
+  pl->unroll = a->unroll > 0 ? a->unroll : ((want_pipe && !ragged) ? (pl->fused_adapters ? 2 : 1) : 4);
   const uint32_t U = (uint32_t)pl->unroll;
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
   uint32_t single_cap = 576u;
@@ -258,6 +259,9 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // threads per CU, and the LDS image must fit as many times
   uint32_t wgs = a->wgs_per_cu > 0 ? (uint32_t)a->wgs_per_cu
                                    : std::max<uint32_t>(1, std::min<uint32_t>(1024 / T, (uint32_t)(160 * 1024 / lds)));
+  // strided batches without the adapter scan: the kernel is built for 64 VGPRs and runs two
+  // workgroups per CU when the LDS holds two histograms (reads of up to ~190 bases)
+  if (strided && !pl->fused_adapters && a->wgs_per_cu <= 0 && T == 1024 && 2 * lds <= 160 * 1024) wgs = 2;
   // Work items = tiles x read slices.  Single tile: one item per resident
   // workgroup.  Several tiles (long reads): reads do not reach the far tiles
   // equally, so the slices are cut ~16x finer than the resident workgroups and
@@ -296,16 +300,28 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
 }
 
 template <int T, int U, int PD>
-int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, bool aligned, dim3 grid,
+int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, bool aligned, bool strided, dim3 grid,
                    size_t lds, hipStream_t st) {
   void (*k)(const qk::HistParams) = nullptr;
+  if (strided) {
+    // fixed stride + per-read lengths: built for the planner's own choice only
+    if (fixed && aligned && mode == 0) {
+      if constexpr (T == 1024 && PD == 2 && U == 1) {
+        if (!adapt) k = qk::hist_kernel<T, U, true, 0, false, PD, true, true>;
+      }
+      if constexpr (T == 1024 && PD == 2 && U == 2) {
+        if (adapt) k = qk::hist_kernel<T, U, true, 0, true, PD, true, true>;
+      }
+    }
+    if (!k) return fail(QK_EINVAL, "strided batches run with the planner's own launch geometry only (threads/unroll/pipe overrides are set)");
+  } else
   if (aligned && !fixed && mode == 0) {
     // only built for the planner's own choice (make_plan sets `aligned` for nothing else)
     if constexpr (T == 1024 && U == 4 && PD == 1)
       k = adapt ? qk::hist_kernel<T, U, false, 0, true, PD, true> : qk::hist_kernel<T, U, false, 0, false, PD, true>;
   }
-  if (aligned && fixed && mode == 0) {
-    if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 4))
+  if (!strided && aligned && fixed && mode == 0) {
+    if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 2))
       k = adapt ? qk::hist_kernel<T, U, true, 0, true, PD, true> : qk::hist_kernel<T, U, true, 0, false, PD, true>;
   }
   if (k) {
@@ -357,11 +373,11 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
 }
 
 int launch_hist(qk_accum *a, const qk::HistParams &hp, const Plan &pl, bool fixed, int mode, bool adapt,
-                hipStream_t st) {
+                hipStream_t st, bool strided = false) {
   const size_t lds = qk::hist_lds_bytes(hp.ch, adapt, hp.bucket_log2, !fixed, pl.stage_reads);
   dim3 grid((unsigned)pl.n_blocks);
 #define QK_TU(TT, UU, PP) \
-  if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, grid, lds, st);
+  if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, strided, grid, lds, st);
   QK_TU(1024, 4, 1) QK_TU(1024, 2, 1) QK_TU(1024, 1, 1)
   QK_TU(1024, 4, 2) QK_TU(1024, 2, 2) QK_TU(1024, 1, 2)
   QK_TU(512, 4, 1) QK_TU(512, 2, 1) QK_TU(512, 1, 1)
@@ -387,7 +403,7 @@ int g_ablation_mode = 0;  // set through qk_debug_set_mode (kbench only)
 int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
                   const uint64_t *d_off, uint32_t *d_hit, uint64_t n_reads,
                   uint64_t total_bytes, uint32_t max_len, hipStream_t st,
-                  const uint32_t *d_len = nullptr, uint32_t flags = 0) {
+                  const uint32_t *d_len = nullptr, uint32_t flags = 0, uint32_t stride = 0) {
   if (n_reads == 0) return QK_OK;
   if (n_reads > 0xFFFFFFF0ull) return fail(QK_EINVAL, "batch too large");
   int rc = grow_table(a, std::max<uint64_t>(max_len, 11));
@@ -397,10 +413,14 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     return QK_OK;
   }
   Plan pl;
-  if (d_len && total_bytes > 0x7FFFFFF0ull) return fail(QK_EINVAL, "a gapped batch must stay below 2 GiB");
-  rc = make_plan(a, n_reads, max_len, d_off != nullptr, d_len != nullptr, d_len && (flags & QK_BATCH_ALIGNED128), &pl,
-                 (((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) == 0);
+  // three batch forms: packed (d_off, no d_len), gapped (d_off = starts, d_len), strided (no d_off, d_len, stride)
+  const bool strided = d_off == nullptr && d_len != nullptr;
+  if (d_off && d_len && total_bytes > 0x7FFFFFF0ull) return fail(QK_EINVAL, "a gapped batch must stay below 2 GiB");
+  rc = make_plan(a, n_reads, strided ? stride : max_len, d_off != nullptr, d_off && d_len,
+                 d_off && d_len && (flags & QK_BATCH_ALIGNED128), &pl, (((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) == 0,
+                 strided);
   if (rc) return rc;
+  if (strided && !pl.aligned) return fail(QK_EINVAL, "strided batches run with the planner's own launch geometry only");
   if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));
   TimedLaunch tl{};
   if (a->timing) {
@@ -411,7 +431,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     tl.b1 = tl.t1;
     // batches with a pre-pass (queue reset, reach sort, length kernel) or an adapter
     // count kernel get their own pair of events around the whole batch
-    if (pl.n_tiles > 1 || a->adapters) {
+    if (pl.n_tiles > 1 || a->adapters || strided) {
       tl.b0 = get_event(a);
       tl.b1 = get_event(a);
       if (!tl.b0 || !tl.b1) return fail(QK_EHIP, "hipEventCreate failed");
@@ -425,7 +445,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.lengths = d_len;
   hp.stage_reads = pl.stage_reads;
   hp.status = a->d_status;
-  hp.check_aligned = (d_len && (flags & QK_BATCH_ALIGNED128)) ? 1u : 0u;
+  hp.check_aligned = (d_off && d_len && (flags & QK_BATCH_ALIGNED128)) ? 1u : 0u;
   if (hp.check_aligned) a->status_armed = true;
   hp.table = a->d_table;
   hp.no_adapters = a->adapters ? 0 : 1;
@@ -438,7 +458,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.n_reads = n_reads;
   hp.total_bytes = total_bytes;
   hp.reads_per_slice = pl.reads_per_slice;
-  hp.read_len = d_off ? 0 : max_len;
+  hp.read_len = d_off ? 0 : (strided ? stride : max_len);
   hp.table_len = (uint32_t)a->table_len;
   hp.n_tiles = pl.n_tiles;
   hp.tile_pos = pl.tile_pos;
@@ -460,11 +480,14 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   // (with two or three tiles nearly every read reaches every tile: nothing to gain)
   pl.sorted = pl.dynamic && d_off != nullptr && total_bytes < 0xFFFFFF00ull && pl.n_tiles >= 4 &&
               pl.n_tiles <= qk::kReachMaxTiles && !getenv("QUACK_HIP_NO_SORT");
-  if (pl.dynamic && d_off != nullptr && !pl.sorted) {
+  if ((pl.dynamic && d_off != nullptr && !pl.sorted) || strided) {
     // several tiles: lengths past the tile width have no LDS counter inside hist_kernel
     // (the sorted path takes them in its counting pass)
-    const unsigned lb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 2048, (uint64_t)a->n_cu * 2));
-    hipLaunchKernelGGL(qk::ragged_length_kernel, dim3(lb), dim3(256), 0, st, hp);
+    const unsigned lb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 8192, (uint64_t)a->n_cu));
+    if (strided && stride <= qk::kShortLen)
+      hipLaunchKernelGGL(qk::short_length_kernel, dim3(lb), dim3(qk::kLenThreads), 0, st, hp);
+    else
+      hipLaunchKernelGGL(qk::ragged_length_kernel, dim3(lb), dim3(qk::kLenThreads), 0, st, hp);
     QK_HIP(hipGetLastError());
     hp.lengths_done = 1;
   }
@@ -500,7 +523,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
 
   if (a->timing) QK_HIP(hipEventRecord(tl.t0, st));
   if (pl.fused_adapters) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
-  rc = launch_hist(a, hp, pl, d_off == nullptr, g_ablation_mode, pl.fused_adapters, st);
+  rc = launch_hist(a, hp, pl, d_off == nullptr, g_ablation_mode, pl.fused_adapters, st, strided);
   if (rc) return rc;
   if (a->timing) QK_HIP(hipEventRecord(tl.t1, st));
   if (a->adapters) {
@@ -995,6 +1018,90 @@ int qk_accum_submit_device_gapped(qk_accum *a, const void *d_seq, const void *d_
   }
   return enqueue_batch(a, (const uint8_t *)d_seq, (const uint8_t *)d_qual, (const uint64_t *)d_starts, d_hit,
                        n_reads, extent_bytes, max_len, st, (const uint32_t *)d_lengths, flags);
+}
+
+int qk_accum_submit_device_strided(qk_accum *a, const void *d_seq, const void *d_qual, const void *d_lengths,
+                                   uint64_t n_reads, uint32_t stride, uint32_t max_len, void *hip_stream) {
+  if (!a || (n_reads && (!d_lengths || (max_len && (!d_seq || !d_qual))))) return fail(QK_EINVAL, "NULL argument");
+  if (stride == 0 || (stride & 3u) || max_len > stride) return fail(QK_EINVAL, "stride must be a multiple of 4 and >= max_len");
+  if ((((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) != 0) return fail(QK_EINVAL, "strided batches must start on a 4-byte boundary");
+  int rc = set_device(a);
+  if (rc) return rc;
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : a->stream;
+  if (hip_stream) a->foreign_stream_used = true;
+  uint32_t *d_hit = nullptr;
+  if (a->adapters) {
+    if (a->hit_scratch_reads < n_reads) {
+      QK_HIP(hipDeviceSynchronize());
+      if (a->d_hit_scratch) QK_HIP(hipFree(a->d_hit_scratch));
+      a->d_hit_scratch = nullptr;
+      a->hit_scratch_reads = 0;
+      QK_HIP(hipMalloc((void **)&a->d_hit_scratch, n_reads * sizeof(uint32_t)));
+      a->hit_scratch_reads = n_reads;
+    }
+    d_hit = a->d_hit_scratch;
+  }
+  return enqueue_batch(a, (const uint8_t *)d_seq, (const uint8_t *)d_qual, nullptr, d_hit, n_reads,
+                       n_reads * (uint64_t)stride, max_len, st, (const uint32_t *)d_lengths, 0, stride);
+}
+
+int qk_accum_submit_strided(qk_accum *a, const uint8_t *seq, const uint8_t *qual, const uint32_t *lengths,
+                            uint32_t stride, uint64_t n_reads) {
+  if (!a || (n_reads && (!lengths || !seq || !qual))) return fail(QK_EINVAL, "NULL argument");
+  if (stride == 0 || (stride & 3u)) return fail(QK_EINVAL, "stride must be a multiple of 4");
+  uint64_t i = 0;
+  while (i < n_reads) {
+    uint8_t *hs, *hq;
+    uint64_t *ho, capb, capr;
+    uint32_t *hl;
+    int rc = qk_accum_acquire(a, &hs, &hq, &ho, &capb, &capr);
+    if (rc) return rc;
+    if ((rc = qk_accum_slot_lengths(a, &hl))) return rc;
+    const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(n_reads - i, capb / stride), capr);
+    if (n == 0) {
+      a->held_slot = -1;
+      return fail(QK_EINVAL, "stride exceeds the batch slot");
+    }
+    memcpy(hs, seq + i * stride, n * stride);
+    memcpy(hq, qual + i * stride, n * stride);
+    memcpy(hl, lengths + i, n * sizeof(uint32_t));
+    if ((rc = qk_accum_commit_strided(a, n, stride))) {
+      a->held_slot = -1;
+      return rc;
+    }
+    i += n;
+  }
+  return QK_OK;
+}
+
+int qk_accum_commit_strided(qk_accum *a, uint64_t n_reads, uint32_t stride) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  if (a->held_slot < 0) return fail(QK_ESTATE, "no batch acquired");
+  if (stride == 0 || (stride & 3u)) return fail(QK_EINVAL, "stride must be a multiple of 4");
+  Slot &s = a->slot[a->held_slot];
+  const uint64_t total = n_reads * (uint64_t)stride;
+  if (total > a->cap_bytes || n_reads > a->cap_reads) return fail(QK_EINVAL, "batch exceeds slot capacity");
+  int rc = set_device(a);
+  if (rc) return rc;
+  uint32_t max_len = 0;
+  for (uint64_t i = 0; i < n_reads; ++i) {
+    if (s.h_len[i] > stride) return fail(QK_EINVAL, "read %llu is longer than the stride", (unsigned long long)i);
+    max_len = std::max(max_len, s.h_len[i]);
+  }
+  a->held_slot = -1;
+  a->next_slot ^= 1;
+  if (n_reads == 0) return QK_OK;
+  if ((rc = grow_table(a, std::max<uint64_t>(max_len, 11)))) return rc;
+  memset(s.h_seq + total, 0, QK_TAIL_SLACK);
+  memset(s.h_qual + total, 0, QK_TAIL_SLACK);
+  QK_HIP(hipMemcpyAsync(s.d_seq, s.h_seq, total + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
+  QK_HIP(hipMemcpyAsync(s.d_qual, s.h_qual, total + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
+  QK_HIP(hipMemcpyAsync(s.d_len, s.h_len, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
+  rc = enqueue_batch(a, s.d_seq, s.d_qual, nullptr, s.d_hit, n_reads, total, max_len, s.stream, s.d_len, 0, stride);
+  if (rc) return rc;
+  QK_HIP(hipEventRecord(s.done, s.stream));
+  s.busy = true;
+  return QK_OK;
 }
 
 int qk_accum_slot_lengths(qk_accum *a, uint32_t **lengths) {

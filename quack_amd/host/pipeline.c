@@ -62,6 +62,8 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
   qk_accum *accs[64];
   qkh_reader *rd = NULL;
   int rc = -1, turn = 0, made = 0, long_reads = 0;
+  uint32_t stride = 0;   /* != 0: short reads of nearly one length, laid out at a fixed stride */
+  const int no_stride = getenv("QUACK_NO_STRIDE") != NULL;
   const int verbose = getenv("QUACK_VERBOSE") != NULL;
   const double t0 = now_s();
   double t_created, t_first = 0, t_parsed;
@@ -92,6 +94,34 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       goto out;
     }
     if (!t_first) t_first = now_s();
+    if (stride) {
+      /* short reads, nearly all of one length (judged by the previous batch; what trimmed
+       * Illumina runs look like): fixed stride + per-read lengths, so that the kernels keep
+       * the addressing and the pipelined loop of a fixed-length batch (qk_accum_commit_strided) */
+      uint32_t *lengths;
+      uint64_t parked;
+      if (qk_accum_slot_lengths(acc, &lengths)) {
+        host_fail("%s", qk_last_error());
+        goto out;
+      }
+      n = qkh_reader_fill_strided(rd, seq, qual, lengths, cap_bytes, cap_reads, stride, &uniform);
+      if (n < 0) {
+        host_fail("%s: out of memory while parsing", path);
+        goto out;
+      }
+      /* all of one length after all, and the stride is that length: a plain fixed-length batch */
+      if (uniform == stride ? qk_accum_commit(acc, (uint64_t)n, (uint64_t)n * stride, 0, stride)
+                            : qk_accum_commit_strided(acc, (uint64_t)n, stride)) {
+        host_fail("%s", qk_last_error());
+        goto out;
+      }
+      /* a read longer than the stride waits: widen the stride if it is still a short read, else go back to
+       * packed batches */
+      parked = qkh_reader_parked_len(rd);
+      if (parked > stride) stride = parked <= 512 ? (uint32_t)((parked + 3) & ~3ull) : 0;
+      turn = (turn + 1) % n_devices;
+      continue;
+    }
     if (long_reads) {
       /* long reads (judged by the previous batch): every read starts on a 128-byte
        * cache line, so that the position tiles the kernels cut them into are whole
@@ -116,6 +146,14 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       goto out;
     }
     if (n > 0) long_reads = total / (uint64_t)n >= 1024 && !getenv("QUACK_NO_ALIGN");
+    if (n > 0 && !long_reads && !uniform && !no_stride) {
+      /* a ragged batch of short reads: is it "one length, some of them trimmed"?  (longest read <= 512:
+       * one position tile; mean >= 3/4 of it: the padding stays below a third of the traffic) */
+      uint64_t longest = 0;
+      for (int64_t i = 0; i < n; i++)
+        if (offsets[i + 1] - offsets[i] > longest) longest = offsets[i + 1] - offsets[i];
+      if (longest >= 16 && longest <= 512 && total * 4 >= (uint64_t)n * longest * 3) stride = (uint32_t)((longest + 3) & ~3ull);
+    }
     turn = (turn + 1) % n_devices;
   }
   t_parsed = now_s();

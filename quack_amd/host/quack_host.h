@@ -46,6 +46,15 @@ int64_t qkh_reader_fill_gapped(qkh_reader *r, uint8_t *seq, uint8_t *qual,
                                uint64_t *starts, uint32_t *lengths, uint64_t cap_bytes,
                                uint64_t cap_reads, uint64_t align,
                                uint64_t *extent_bytes, uint32_t *uniform_len);
+/* Same, into a strided batch (qk_accum_commit_strided): read i is written at
+ * i * stride and is lengths[i] long.  The batch ends in front of the first read
+ * longer than the stride (it waits for the next batch: qkh_reader_parked_len);
+ * returns 0 without consuming anything when that read is the first one. */
+int64_t qkh_reader_fill_strided(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint32_t *lengths,
+                                uint64_t cap_bytes, uint64_t cap_reads, uint32_t stride,
+                                uint32_t *uniform_len);
+/* length of the record that did not fit the last batch and opens the next one (0: none) */
+uint64_t qkh_reader_parked_len(const qkh_reader *r);
 /* 1 once the stream is exhausted (or stopped by a malformed record) */
 int qkh_reader_done(const qkh_reader *r);
 

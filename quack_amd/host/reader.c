@@ -247,18 +247,26 @@ static size_t fast_record(qkh_reader *r, uint8_t *seq_dst, uint8_t *qual_dst, si
 
 /* One batch.  Read i is written at starts[i], the end of its predecessor
  * rounded up to `align`; lengths may be NULL (packed batches: the caller reads
- * the ends off the next start). */
+ * the ends off the next start).  stride != 0: read i is written at i * stride
+ * instead (starts may be NULL), and the batch ends in front of the first read
+ * that is longer than the stride — it is parked for the next batch. */
 static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *starts, uint32_t *lengths,
                           uint64_t cap_bytes, uint64_t cap_reads, uint64_t align, uint64_t *extent,
-                          uint32_t *uniform_len) {
+                          uint32_t *uniform_len, uint64_t stride) {
   uint64_t n = 0, total = 0;   /* total = end of the last read */
   int64_t common = -1;         /* -1 unknown, -2 mixed */
+  if (stride && cap_reads > cap_bytes / stride) cap_reads = cap_bytes / stride;
   if (r->have_parked) {
+    if (stride && r->park_len > stride) {     /* the caller has to pick another layout first */
+      *extent = 0;
+      *uniform_len = 0;
+      return 0;
+    }
     if (r->park_len > cap_bytes) return -4;   /* a single read exceeds the batch */
     memcpy(seq, r->park_seq, r->park_len);
     if (r->parked_is_fastq) memcpy(qual, r->park_qual, r->park_len);
     else memset(qual, 0, r->park_len);
-    starts[0] = 0;
+    if (starts) starts[0] = 0;
     if (lengths) lengths[0] = (uint32_t)r->park_len;
     total = r->park_len;
     n = 1;
@@ -266,12 +274,13 @@ static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *
     r->have_parked = 0;
   }
   while (!r->finished && n < cap_reads) {
-    const uint64_t at = (total + align - 1) & ~(align - 1);
+    const uint64_t at = stride ? n * stride : (total + align - 1) & ~(align - 1);
+    const uint64_t room = stride ? stride : cap_bytes - at;
     if (at >= cap_bytes && n > 0) break;      /* no room left for another start */
-    const size_t fl = fast_record(r, seq + at, qual + at, cap_bytes - at);
+    const size_t fl = fast_record(r, seq + at, qual + at, room);
     if (fl) {
       if (fl > 0xFFFFFFFFull) return -4;
-      starts[n] = at;
+      if (starts) starts[n] = at;
       if (lengths) lengths[n] = (uint32_t)fl;
       n++;
       total = at + fl;
@@ -279,8 +288,8 @@ static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *
       else if (common != (int64_t)fl) common = -2;
       continue;
     }
-    sink sq = {seq + at, 0, cap_bytes - at, &r->park_seq, &r->park_seq_cap, 0};
-    sink ql = {qual + at, 0, cap_bytes - at, &r->park_qual, &r->park_qual_cap, 0};
+    sink sq = {seq + at, 0, room, &r->park_seq, &r->park_seq_cap, 0};
+    sink ql = {qual + at, 0, room, &r->park_qual, &r->park_qual_cap, 0};
     int is_fastq = 0;
     long l = parse_record(r, &sq, &ql, &is_fastq);
     if (l == -3) return -3;
@@ -295,11 +304,11 @@ static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *
       r->park_len = (size_t)l;
       r->have_parked = 1;
       r->parked_is_fastq = is_fastq;
-      if (n == 0 && (uint64_t)l > cap_bytes) return -4;
+      if (n == 0 && !stride && (uint64_t)l > cap_bytes) return -4;
       break;
     }
     if (!is_fastq) memset(qual + at, 0, (size_t)l);  /* FASTA fed as reads: no scores */
-    starts[n] = at;
+    if (starts) starts[n] = at;
     if (lengths) {
       if ((uint64_t)l > 0xFFFFFFFFull) return -4;
       lengths[n] = (uint32_t)l;
@@ -320,7 +329,7 @@ int64_t qkh_reader_fill(qkh_reader *r, uint8_t *seq, uint8_t *qual,
                         uint32_t *uniform_len) {
   int64_t n;
   offsets[0] = 0;
-  n = fill_batch(r, seq, qual, offsets, NULL, cap_bytes, cap_reads, 1, total_bytes, uniform_len);
+  n = fill_batch(r, seq, qual, offsets, NULL, cap_bytes, cap_reads, 1, total_bytes, uniform_len, 0);
   if (n >= 0) offsets[n] = *total_bytes;   /* packed: read i ends where i+1 starts */
   return n;
 }
@@ -330,8 +339,17 @@ int64_t qkh_reader_fill_gapped(qkh_reader *r, uint8_t *seq, uint8_t *qual,
                                uint64_t cap_reads, uint64_t align,
                                uint64_t *extent_bytes, uint32_t *uniform_len) {
   if (!align || (align & (align - 1)) || !lengths) return -3;
-  return fill_batch(r, seq, qual, starts, lengths, cap_bytes, cap_reads, align, extent_bytes, uniform_len);
+  return fill_batch(r, seq, qual, starts, lengths, cap_bytes, cap_reads, align, extent_bytes, uniform_len, 0);
 }
+
+int64_t qkh_reader_fill_strided(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint32_t *lengths,
+                                uint64_t cap_bytes, uint64_t cap_reads, uint32_t stride, uint32_t *uniform_len) {
+  uint64_t extent;
+  if (!stride || !lengths) return -3;
+  return fill_batch(r, seq, qual, NULL, lengths, cap_bytes, cap_reads, 1, &extent, uniform_len, stride);
+}
+
+uint64_t qkh_reader_parked_len(const qkh_reader *r) { return r->have_parked ? (uint64_t)r->park_len : 0; }
 
 /* ----------------------------------------------------------------- adapters */
 

@@ -37,7 +37,7 @@ struct qk_accum {
   uint32_t *len[2];
   int next, held;
   uint64_t cap_bytes, cap_reads;
-  unsigned long commits, gapped_commits, aligned_commits;
+  unsigned long commits, gapped_commits, aligned_commits, strided_commits;
 };
 
 int qk_accum_create(qk_accum **out, int device, const uint32_t *bits, uint64_t hint) {
@@ -66,7 +66,8 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *bits, uint64_t h
 void qk_accum_destroy(qk_accum *a) {
   if (!a) return;
   if (getenv("QK_DOUBLE_VERBOSE"))
-    fprintf(stderr, "[double] commits %lu gapped %lu aligned %lu\n", a->commits, a->gapped_commits, a->aligned_commits);
+    fprintf(stderr, "[double] commits %lu gapped %lu aligned %lu strided %lu\n", a->commits, a->gapped_commits,
+            a->aligned_commits, a->strided_commits);
   for (int i = 0; i < 2; i++) {
     free(a->seq[i]);
     free(a->qual[i]);
@@ -129,6 +130,21 @@ int qk_accum_commit_gapped(qk_accum *a, uint64_t n, uint64_t extent, uint32_t fl
   a->aligned_commits += (flags & QK_BATCH_ALIGNED128) != 0;
   for (uint64_t i = 0; i < n; i++)
     oracle_accumulate_read(&a->t, a->seq[s] + a->off[s][i], a->qual[s] + a->off[s][i], a->len[s][i], a->kmers);
+  return QK_OK;
+}
+
+int qk_accum_commit_strided(qk_accum *a, uint64_t n, uint32_t stride) {
+  if (a->held < 0) return fail(QK_ESTATE, "no batch acquired");
+  const int s = a->held;
+  if (stride == 0 || (stride & 3u)) return fail(QK_EINVAL, "stride must be a multiple of 4");
+  if (n * (uint64_t)stride > a->cap_bytes || n > a->cap_reads) return fail(QK_EINVAL, "batch exceeds slot capacity");
+  for (uint64_t i = 0; i < n; i++)
+    if (a->len[s][i] > stride) return fail(QK_EINVAL, "read longer than the stride");
+  release(a);
+  a->commits++;
+  a->strided_commits++;
+  for (uint64_t i = 0; i < n; i++)
+    oracle_accumulate_read(&a->t, a->seq[s] + i * stride, a->qual[s] + i * stride, a->len[s][i], a->kmers);
   return QK_OK;
 }
 

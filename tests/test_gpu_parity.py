@@ -591,3 +591,93 @@ def test_device_table_roundtrip_and_single_rank_allreduce():
         assert_same((sd.bases, sd.number_of_sequences), want)
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- strided batches (fixed stride, own lengths)
+def strided_from_ragged(seq, qual, off, stride, fill=None):
+    """the reads of a packed batch laid out at a fixed stride; the bytes behind a read's last base are
+    garbage on purpose (letters and scores that must never be counted)"""
+    lens = np.diff(off.astype(np.int64))
+    n = len(lens)
+    rng = np.random.default_rng(5)
+    s2 = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * stride)].copy() if fill is None else np.full(n * stride, fill, np.uint8)
+    q2 = (33 + rng.integers(0, 60, n * stride)).astype(np.uint8) if fill is None else np.full(n * stride, fill, np.uint8)
+    idx = (np.arange(n, dtype=np.int64) * stride).repeat(lens) + (np.arange(int(off[-1]), dtype=np.int64) - off[:-1].astype(np.int64).repeat(lens))
+    s2[idx] = seq
+    q2[idx] = qual
+    return s2, q2, lens.astype(np.uint32)
+
+
+@pytest.mark.parametrize("n,lo,hi,stride,adapters", [(30000, 120, 150, 152, False), (30000, 120, 150, 152, True),
+                                                     (20000, 0, 151, 152, False), (50000, 1, 36, 36, True),
+                                                     (5000, 250, 300, 300, True), (3000, 500, 1000, 1000, False),
+                                                     (2000, 400, 1200, 1200, True), (1, 7, 7, 8, False)])
+def test_strided_batches(n, lo, hi, stride, adapters):
+    """trimmed-Illumina form: equals the oracle on the same reads packed; host feed and device feed"""
+    import torch
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads) if adapters else None
+    bits = ob.kmers_to_bitset(k) if adapters else None
+    seq, qual, off = synth.ragged(n, lo, hi, seed=n + hi, q_lo=1, q_hi=60, alphabet=b"ACGTNacgt")
+    seq = seq.copy()
+    rng = np.random.default_rng(3)
+    if adapters:
+        for r in rng.integers(0, n, n // 4):            # an adapter somewhere in a quarter of the reads
+            a, e = int(off[r]), int(off[r + 1])
+            ad = np.frombuffer(ads[r % len(ads)], np.uint8)
+            if e - a > 12:
+                at = a + int(rng.integers(0, e - a - 10))
+                m = min(len(ad), e - at)
+                seq[at:at + m] = ad[:m]
+    want = ob.accumulate_batch(seq, qual, off, kmers=k)
+    s2, q2, lens = strided_from_ragged(seq, qual, off, stride)
+    with quack_amd.Accumulator(0, bits) as acc:
+        acc.submit_strided(s2, q2, lens, stride)                       # pinned slots
+        d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+        d_l = torch.from_numpy(lens.astype(np.int32)).cuda()
+        acc.submit_device_strided(d_s, d_q, d_l, n, stride, int(lens.max()))
+        sd = acc.finish()
+    assert sd.number_of_sequences == 2 * want[1]
+    assert_same((sd.bases, want[1]), (2 * want[0], want[1]))
+
+
+def test_strided_rejects_bad_geometry():
+    with quack_amd.Accumulator(0) as acc:
+        with pytest.raises(quack_amd.HipUnavailable):
+            acc.submit_strided(np.zeros(30, np.uint8), np.zeros(30, np.uint8), np.array([3, 3, 3], np.uint32), 10)   # stride % 4
+        with pytest.raises(quack_amd.HipUnavailable):
+            acc.submit_strided(np.zeros(24, np.uint8), np.zeros(24, np.uint8), np.array([3, 9, 3], np.uint32), 8)    # read > stride
+
+
+def test_host_feed_lays_trimmed_reads_out_at_a_fixed_stride(tmp_path, monkeypatch):
+    """whole-file path on short reads of nearly one length: from the second batch on the tokenizer writes
+    them at a fixed stride (qk_accum_commit_strided); same counters as the oracle, as the packed feed
+    (QUACK_NO_STRIDE=1), and through three accumulators; with a read that widens the stride and one that
+    ends the mode"""
+    monkeypatch.setenv("QUACK_HIP_BATCH_MB", "1")
+    rng = np.random.default_rng(12)
+    n = 60000
+    lens = np.where(rng.random(n) < 0.7, 150, rng.integers(100, 150, n))
+    lens[20000], lens[40000], lens[50000] = 163, 2000, 0
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(off[-1])
+    seq = np.frombuffer(b"ACGTNacgt", np.uint8)[rng.integers(0, 9, total)]
+    qual = (33 + rng.integers(0, 42, total)).astype(np.uint8)
+    fq = tmp_path / "trimmed.fq"
+    with open(fq, "wb") as f:
+        for r in range(n):
+            a, b = int(off[r]), int(off[r + 1])
+            f.write(b"@r%d\n" % r + seq[a:b].tobytes() + b"\n+\n" + qual[a:b].tobytes() + b"\n")
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    for kmers, bits in ((None, None), (k, ob.kmers_to_bitset(k))):
+        want = ob.read_fastq(str(fq), kmers)
+        assert want[1] == n
+        sd = quack_amd.read_fastq(str(fq), bits)
+        assert_same((sd.bases, sd.number_of_sequences), want)
+        sd3 = quack_amd.read_fastq(str(fq), bits, devices=(0, 0, 0))
+        assert_same((sd3.bases, sd3.number_of_sequences), want)
+        monkeypatch.setenv("QUACK_NO_STRIDE", "1")
+        sd = quack_amd.read_fastq(str(fq), bits)
+        monkeypatch.delenv("QUACK_NO_STRIDE")
+        assert_same((sd.bases, sd.number_of_sequences), want)

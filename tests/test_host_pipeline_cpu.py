@@ -61,9 +61,47 @@ def test_long_reads_switch_to_cache_line_batches(quack_double, tmp_path):
     b = run(quack_double, ["-u", str(fq)], QK_DOUBLE_VERBOSE="1", QUACK_NO_ALIGN="1")
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 1000
     stats = lambda r: [int(t) for t in r.stderr.decode().split("[double]")[1].split() if t.isdigit()]
-    commits, gapped, aligned = stats(a)
-    assert commits > 5 and gapped == aligned == commits - 1, a.stderr     # all but the first batch
-    assert stats(b)[1:] == [0, 0]
+    commits, gapped, aligned, strided = stats(a)
+    assert commits > 5 and gapped == aligned == commits - 1 and strided == 0, a.stderr     # all but the first batch
+    assert stats(b)[1:] == [0, 0, 0]
+
+
+def write_fastq(path, lens, g):
+    with open(path, "wb") as f:
+        for r, n in enumerate(lens):
+            f.write(b"@r%d\n" % r + g.choice(np.frombuffer(b"ACGTN", np.uint8), n).tobytes() + b"\n+\n" +
+                    g.integers(35, 70, n).astype(np.uint8).tobytes() + b"\n")
+
+
+def test_trimmed_short_reads_switch_to_strided_batches(quack_double, tmp_path):
+    """reads of nearly one length (trimmed Illumina): from the second batch on the pipeline lays them out at a
+    fixed stride (qk_accum_commit_strided); a longer read widens the stride, a long one ends the mode; the
+    SVG is the packed pipeline's (QUACK_NO_STRIDE=1) byte for byte"""
+    g = np.random.default_rng(9)
+    lens = np.where(g.random(6000) < 0.7, 150, g.integers(120, 150, 6000))
+    lens[3000] = 170          # longer than the stride of 152: the stride grows to 172
+    lens[4500] = 900          # not a short read any more: back to packed batches (and then to strided again)
+    fq = tmp_path / "trimmed.fq"
+    write_fastq(fq, lens, g)
+    stats = lambda r: [int(t) for t in r.stderr.decode().split("[double]")[1].split() if t.isdigit()]
+    for extra in ({}, {"QUACK_DEVICES": "0,1"}):
+        extra = dict(extra, QK_DOUBLE_SLOT_BYTES="20000")
+        a = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], QK_DOUBLE_VERBOSE="1", **extra)
+        b = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], QK_DOUBLE_VERBOSE="1", QUACK_NO_STRIDE="1", **extra)
+        assert a.returncode == 0 and b.returncode == 0, a.stderr[-2000:]
+        assert a.stdout == b.stdout and len(a.stdout) > 1000
+        commits, gapped, aligned, strided = stats(a)
+        assert gapped == 0 and strided >= commits - 6 and strided > 10, a.stderr
+        assert stats(b)[3] == 0
+
+
+def test_equal_length_reads_stay_fixed_length_batches(quack_double, tmp_path):
+    g = np.random.default_rng(10)
+    fq = tmp_path / "fixed.fq"
+    write_fastq(fq, [100] * 3000, g)
+    a = run(quack_double, ["-u", str(fq)], QK_DOUBLE_VERBOSE="1")
+    assert a.returncode == 0
+    assert [int(t) for t in a.stderr.decode().split("[double]")[1].split() if t.isdigit()][3] == 0
 
 
 def test_a_read_larger_than_a_slot_is_an_error_not_a_truncation(quack_double):

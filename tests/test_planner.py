@@ -45,7 +45,7 @@ def test_plans_fit_the_hardware(ragged, adapters):
         assert p["row_dwords"] % 32 == 0 and p["row_dwords"] >= 4 * p["replicas"] * p["ch"], ctx  # bank == column
         assert p["dynamic"] == (p["n_tiles"] > 1), ctx
         assert p["n_blocks"] >= 1 and (p["dynamic"] or p["n_blocks"] == p["n_slices"]), ctx
-        assert (p["unroll"], p["pipe"]) == ((4, 1) if ragged else ((4, 2) if adapters else (1, 2))), ctx
+        assert (p["unroll"], p["pipe"]) == ((4, 1) if ragged else ((2, 2) if adapters else (1, 2))), ctx
         # fixed-length reads of a multiple of 4 bases take the dword-aligned variant (one dwordx2 per chunk)
         assert p["aligned"] == (not ragged and max_len % 4 == 0), ctx
 
