@@ -244,6 +244,7 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false>
 __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
   static_assert(!SV || (FIXED && AL), "strided batches are a variant of the dword-aligned fixed-length path");
+  constexpr bool STAGED = !FIXED;   // ragged batches: the read list is staged in LDS pass by pass
   extern __shared__ uint32_t lds_raw[];
   // ADAPT: the window filter sits first, so that the probes' LDS addresses are
   // "field + constant" (no per-probe add of a layout-dependent base)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   uint4 *lds_buckets = reinterpret_cast<uint4 *>(lds_misc + 4u);
   uint2 *lds_list = reinterpret_cast<uint2 *>(
       reinterpret_cast<char *>(lds_misc + 4u) + ((ADAPT && p.bucket_log2) ? (16u << p.bucket_log2) : 0u));
-  const uint32_t SR = FIXED ? kStageReads : p.stage_reads;
+  const uint32_t SR = STAGED ? p.stage_reads : kStageReads;
   uint32_t *lds_ridx = reinterpret_cast<uint32_t *>(lds_list + SR);   // ADAPT: index of a staged read within its pass
   const uint64_t TL = p.table_len;
 
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
     const uint64_t base_al = slice_base & ~3ull;
     const uint8_t *qbase = p.qual + base_al;
     const uint8_t *sbase = p.seq + base_al;
-    const uint64_t *obase = FIXED ? nullptr : p.offsets + (sorted ? 0 : r_begin);
+    const uint64_t *obase = STAGED ? p.offsets + (sorted ? 0 : r_begin) : nullptr;
     const uint32_t *ord = sorted ? p.order + r_begin : nullptr;
     const uint64_t room = p.total_bytes - base_al;   // total_bytes >= base_al when slice_reads > 0
     const uint32_t off_limit = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
@@ -464,19 +465,19 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
     // round trip and never spends a slot on a read that ends before the tile.
     // the offsets of the next pass are requested one pass ahead (each thread
     // stages the read `tid` of a pass), so staging never waits on memory
-    const uint32_t *lbase = (FIXED || !p.lengths) ? nullptr : p.lengths + (sorted ? 0 : r_begin);
+    const uint32_t *lbase = (!STAGED || !p.lengths) ? nullptr : p.lengths + (sorted ? 0 : r_begin);
     // read number `i` of the slice -> index into offsets[] / lengths[] (relative to obase / lbase)
     auto read_id = [&](uint32_t i) { return ord ? ord[i] : i; };
     uint64_t pf0 = 0, pf1 = 0;
     uint32_t pfid = 0;
-    if (!FIXED && tid < slice_reads) {
+    if (STAGED && tid < slice_reads) {
       pfid = read_id(tid);
       pf0 = obase[pfid];
       pf1 = lbase ? pf0 + lbase[pfid] : obase[pfid + 1u];
     }
-    for (uint32_t pass = 0; pass < slice_reads; pass += FIXED ? slice_reads : SR) {
+    for (uint32_t pass = 0; pass < slice_reads; pass += STAGED ? SR : slice_reads) {
       uint32_t n_list = slice_reads;   // FIXED: every read of the slice
-      if (!FIXED) {
+      if (STAGED) {
         const uint32_t nb = slice_reads - pass < SR ? slice_reads - pass : SR;
         static_assert(T == 1024 || T == 512 || T == 256, "staging assumes kStageReads is a multiple of T");
         __syncthreads();               // the previous pass has been consumed
@@ -596,12 +597,12 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             q[u] = load8_aligned(qbase + off);
             s[u] = load8_aligned(sbase + off);
           } else if (AL) {
-            q[u] = u32x3{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            s[u] = q[u];
-            if (n_raw != 0) {
-              q[u] = load8_aligned(qbase + off);
-              s[u] = load8_aligned(sbase + off);
-            }
+            // chunks past the end of their read fetch the slice's first line instead (hot in
+            // the cache, and every byte of it is masked anyway): cheaper than giving the
+            // registers defaults and loading under an exec mask (6 v_mov + 3 per read)
+            off = n_raw != 0 ? off : 0u;
+            q[u] = load8_aligned(qbase + off);
+            s[u] = load8_aligned(sbase + off);
           } else if (FIXED) {
             q[u] = load12_aligned(qbase + off);
             s[u] = load12_aligned(sbase + off);
@@ -692,14 +693,24 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
         // slice, feeder and halo lanes) sit the counting out under the exec mask.
         // (a ragged wave whose lanes all hold 8 valid bytes — the inside of long
         // reads — skips the mask arithmetic: a wave-uniform branch)
+        // Everything the tail masks cost sits in ONE wave-uniform branch: the masks, their ORs into
+        // the bytes and the count of masked events.  Waves whose lanes all hold 8 valid bytes — the
+        // inside of long reads — skip it.
         uint32_t m0 = 0u, m1 = 0u;
+        uint32_t qw[2] = {qa.x, qa.y}, sw[2] = {sa.x, sa.y};
         if (!FAST_FIXED && __builtin_amdgcn_ballot_w64(n != 8u) != 0) {
           m0 = n >= 4u ? 0u : (0xFFFFFFFFu << (8u * n));
           m1 = n >= 8u ? 0u : (n <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (n - 4u))));
+          qw[0] |= m0;
+          qw[1] |= m1;
+          sw[0] |= m0;
+          sw[1] |= m1;
+          if (MODE == 0 || MODE == 3) {   // (every lane, also with n == 0: all of its bytes are masked in this event)
+            acc_v[0] += m0 & 0x01010101u;   // events in which the byte was masked
+            acc_v[1] += m1 & 0x01010101u;
+          }
         }
         const uint32_t mk[2] = {m0, m1};
-        const uint32_t qw[2] = {qa.x | m0, qa.y | m1};
-        const uint32_t sw[2] = {sa.x | m0, sa.y | m1};
         if (MODE == 1) {
           keep ^= qw[0] ^ qw[1] ^ sw[0] ^ sw[1];
           continue;
@@ -736,7 +747,6 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
               acc_t[d] += nt[d] | inv01;
               acc_c[d] += nc[d] | inv01;
               acc_g[d] += ng[d] | inv01;
-              if (!FAST_FIXED) acc_v[d] += mk[d] & 0x01010101u;   // events in which the byte was masked
             }
             if (FAST_FIXED) steps_v += 1u;
           }
@@ -764,7 +774,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             for (int m = 0; m < 4; ++m) bytU[u][m] = lds_abs_u8(__builtin_amdgcn_ubfe(plo, 2 * (7 - 2 * m) + 3, kFusedFilterLog2 - 3));
           }
         }
-      }
+            }
       if (ADAPT && MODE == 0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -823,12 +833,12 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
           }
         }
       } else {
-        if (!FIXED) load_desc(0u);
+        if (STAGED) load_desc(0u);
         for (uint32_t it = 0; it < n_list; it += RW * U) {
           u32x3 q[U], s[U];
           uint32_t nv[U], sk[U], rl[U];
           issue(it, q, s, nv, sk, rl);
-          if (!FIXED) load_desc(it + RW * U);
+          if (STAGED) load_desc(it + RW * U);
           consume(q, s, nv, sk, rl);
         }
       }
@@ -940,6 +950,40 @@ __device__ __forceinline__ uint32_t tiles_reached(const HistParams &p, uint64_t 
   return k < p.n_tiles ? k : p.n_tiles;
 }
 
+// cnt[key] += 1 for every lane with `valid`, adding lanes that hold the same key up
+// first: real batches are dominated by one or two lengths, and 64 lanes adding to
+// one LDS address serialise (10M reads, 70 % of one length: 53 us -> 12 us)
+__device__ __forceinline__ void wave_count_lds(uint32_t *cnt, uint32_t key, bool valid) {
+  uint64_t left = __builtin_amdgcn_ballot_w64(valid);
+  const uint32_t lane = threadIdx.x & 63u;
+  for (int k = 0; k < 3 && left; ++k) {
+    const uint32_t leader = (uint32_t)__builtin_ctzll(left);
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)leader);
+    const uint64_t same = __builtin_amdgcn_ballot_w64(valid && key == v);
+    if (lane == leader) atomicAdd(&cnt[v], (uint32_t)__builtin_popcountll(same));
+    if (key == v) valid = false;
+    left &= ~same;
+  }
+  if (valid) atomicAdd(&cnt[key], 1u);
+}
+
+// the same on a row of the u64 table in global memory (lengths past the LDS counters: long reads
+// come in few copies per length — unless the batch is, say, 143k reads of exactly 10,496 bases:
+// same-address global atomics serialise at ~15 ns, 1.7 ms for that batch)
+__device__ __forceinline__ void wave_count_global(unsigned long long *row, uint32_t key, bool valid) {
+  uint64_t left = __builtin_amdgcn_ballot_w64(valid);
+  const uint32_t lane = threadIdx.x & 63u;
+  for (int k = 0; k < 3 && left; ++k) {
+    const uint32_t leader = (uint32_t)__builtin_ctzll(left);
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)leader);
+    const uint64_t same = __builtin_amdgcn_ballot_w64(valid && key == v);
+    if (lane == leader) atomicAdd(&row[v], (unsigned long long)__builtin_popcountll(same));
+    if (key == v) valid = false;
+    left &= ~same;
+  }
+  if (valid) atomicAdd(&row[key], 1ull);
+}
+
 // counts[k] += reads of bucket k (counts: n_tiles + 1 words, zero on entry and
 // on exit), and the batch's length_count / kmers==NULL count while the lengths
 // are in hand; the block that finishes last turns the counts into
@@ -956,15 +1000,16 @@ __global__ __launch_bounds__(kReachThreads) void reach_count_kernel(const HistPa
   if (threadIdx.x == 0) gt10 = 0;
   __syncthreads();
   uint32_t mine = 0;
-  for (uint64_t r = (uint64_t)blockIdx.x * kReachThreads + threadIdx.x; r < p.n_reads; r += (uint64_t)gridDim.x * kReachThreads) {
-    const uint32_t len = p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]);
+  // (whole waves per round: the wave_count_* helpers use ballots)
+  for (uint64_t r0 = (uint64_t)blockIdx.x * kReachThreads; r0 < p.n_reads; r0 += (uint64_t)gridDim.x * kReachThreads) {
+    const uint64_t r = r0 + threadIdx.x;
+    const bool in = r < p.n_reads;
+    const uint32_t len = !in ? 0u : (p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]));
     const uint32_t k = (len + p.tile_pos - 1u) / p.tile_pos;
-    atomicAdd(&lc[k < p.n_tiles ? k : p.n_tiles], 1u);
+    wave_count_lds(lc, k < p.n_tiles ? k : p.n_tiles, in);
     mine += len > 10u ? 1u : 0u;
-    if (len) {
-      if (len - 1u < kLenLds) atomicAdd(&len_cnt[len - 1u], 1u);
-      else atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + len - 1u], 1ull);
-    }
+    wave_count_lds(len_cnt, len - 1u, len != 0 && len - 1u < kLenLds);
+    wave_count_global(&p.table[(uint64_t)kRowLength * p.table_len], len - 1u, len != 0 && len - 1u >= kLenLds);
   }
   if (mine) atomicAdd(&gt10, mine);
   __syncthreads();
@@ -1021,23 +1066,6 @@ __global__ __launch_bounds__(kReachThreads) void reach_scatter_kernel(const Hist
   }
 }
 
-// cnt[key] += 1 for every lane with `valid`, adding lanes that hold the same key up
-// first: real batches are dominated by one or two lengths, and 64 lanes adding to
-// one LDS address serialise (10M reads, 70 % of one length: 53 us -> 12 us)
-__device__ __forceinline__ void wave_count_lds(uint32_t *cnt, uint32_t key, bool valid) {
-  uint64_t left = __builtin_amdgcn_ballot_w64(valid);
-  const uint32_t lane = threadIdx.x & 63u;
-  for (int k = 0; k < 3 && left; ++k) {
-    const uint32_t leader = (uint32_t)__builtin_ctzll(left);
-    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)leader);
-    const uint64_t same = __builtin_amdgcn_ballot_w64(valid && key == v);
-    if (lane == leader) atomicAdd(&cnt[v], (uint32_t)__builtin_popcountll(same));
-    if (key == v) valid = false;
-    left &= ~same;
-  }
-  if (valid) atomicAdd(&cnt[key], 1u);
-}
-
 // length_count and the kmers==NULL count (quack.c:215-219) of a ragged batch
 // that spans several tiles.  Inside hist_kernel only lengths below the tile
 // width have an LDS counter; longer ones would be one global atomic per read —
@@ -1058,7 +1086,7 @@ __global__ __launch_bounds__(kLenThreads) void ragged_length_kernel(const HistPa
     mine += (in && len > 10u) ? 1u : 0u;
     const uint32_t lp = len - 1u;
     wave_count_lds(cnt, lp, in && len != 0 && lp < kLenLds);
-    if (in && len != 0 && lp >= kLenLds) atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + lp], 1ull);
+    wave_count_global(&p.table[(uint64_t)kRowLength * p.table_len], lp, in && len != 0 && lp >= kLenLds);
   };
   // (whole waves per round: wave_count_lds uses ballots)
   if (p.lengths && (reinterpret_cast<uintptr_t>(p.lengths) & 15u) == 0) {

@@ -223,7 +223,11 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   if (tile_pos == 0) tile_pos = 8;
   // reads that start on cache lines: tiles of whole cache lines (every line is
   // then fetched by exactly one workgroup); only worth it with several tiles
+#ifdef QK_ABLATION
+  pl->aligned = aligned && ragged && n_tiles > 1 && cap >= 128 && T == 1024;
+#else
   pl->aligned = aligned && ragged && n_tiles > 1 && cap >= 128 && T == 1024 && !a->unroll && !a->pipe;
+#endif
   if (pl->aligned) {
     tile_pos = cap / 128 * 128;
     n_tiles = (max_len + tile_pos - 1) / tile_pos;
@@ -319,6 +323,10 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
     // only built for the planner's own choice (make_plan sets `aligned` for nothing else)
     if constexpr (T == 1024 && U == 4 && PD == 1)
       k = adapt ? qk::hist_kernel<T, U, false, 0, true, PD, true> : qk::hist_kernel<T, U, false, 0, false, PD, true>;
+#ifdef QK_ABLATION   /* kbench / experiments: other step shapes of the cache-line variant */
+    if constexpr (T == 1024 && ((U == 2 && PD == 2) || (U == 4 && PD == 2) || (U == 1 && PD == 2) || (U == 2 && PD == 1)))
+      if (!adapt) k = qk::hist_kernel<T, U, false, 0, false, PD, true>;
+#endif
   }
   if (!strided && aligned && fixed && mode == 0) {
     if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 2))

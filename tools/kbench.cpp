@@ -167,10 +167,15 @@ int main(int argc, char **argv) {
   int h2d = argc > 8 ? atoi(argv[8]) : 0;   // 1: also time the pinned H2D pipeline
 
   // ---- synthetic batch -------------------------------------------------
+  // KB_ALIGNED=1 (ragged): every read starts on a 128-byte line (gapped batch, QK_BATCH_ALIGNED128) —
+  // the layout the host feed gives long reads
+  const bool gapped = ragged && getenv("KB_ALIGNED") != nullptr;
   std::vector<uint64_t> off(n_reads + 1);
-  uint64_t seed = 2, total = 0;
+  std::vector<uint32_t> lens(n_reads);
+  uint64_t seed = 2, total = 0, n_bases = 0;
   uint32_t max_len = 0;
   for (uint64_t r = 0; r < n_reads; ++r) {
+    if (gapped) total = (total + 127) & ~127ull;
     off[r] = total;
     uint32_t l = read_len;
     if (ragged) {
@@ -178,7 +183,9 @@ int main(int argc, char **argv) {
       l = lo + (uint32_t)(splitmix(seed) % (read_len - lo + 1));
     }
     if (l > max_len) max_len = l;
+    lens[r] = l;
     total += l;
+    n_bases += l;
   }
   off[n_reads] = total;
   std::vector<uint8_t> seq(total + QK_TAIL_SLACK, 0), qual(total + QK_TAIL_SLACK, 0);
@@ -223,8 +230,8 @@ int main(int argc, char **argv) {
       }
     }
   }
-  printf("batch: %llu reads, %llu bases, max_len %u, ragged=%d adapters=%d\n",
-         (unsigned long long)n_reads, (unsigned long long)total, max_len, ragged, adapters);
+  printf("batch: %llu reads, %llu bases, max_len %u, ragged=%d adapters=%d%s\n",
+         (unsigned long long)n_reads, (unsigned long long)n_bases, max_len, ragged, adapters, gapped ? " (reads on 128-byte lines)" : "");
 
   uint8_t *d_seq, *d_qual;
   uint64_t *d_off = nullptr;
@@ -235,17 +242,24 @@ int main(int argc, char **argv) {
   printf("d_seq %p d_qual %p (shift %zu)\n", (void *)d_seq, (void *)d_qual, qual_shift);
   HK(hipMemcpy(d_seq, seq.data(), total + QK_TAIL_SLACK, hipMemcpyHostToDevice));
   HK(hipMemcpy(d_qual, qual.data(), total + QK_TAIL_SLACK, hipMemcpyHostToDevice));
+  uint32_t *d_len = nullptr;
   if (ragged) {
     HK(hipMalloc((void **)&d_off, (n_reads + 1) * 8));
     HK(hipMemcpy(d_off, off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    HK(hipMalloc((void **)&d_len, n_reads * 4));
+    HK(hipMemcpy(d_len, lens.data(), n_reads * 4, hipMemcpyHostToDevice));
   }
+  auto submit = [&](qk_accum *acc) {
+    return gapped ? qk_accum_submit_device_gapped(acc, d_seq, d_qual, d_off, d_len, n_reads, total, max_len, QK_BATCH_ALIGNED128, nullptr)
+                  : qk_accum_submit_device(acc, d_seq, d_qual, d_off, n_reads, total, max_len, nullptr);
+  };
 
   // ---- correctness: one submit on a fresh accumulator vs a host count ----
   if (!skip_check) {
     qk_accum *acc;
     CK(qk_accum_create(&acc, 0, adapters ? bits.data() : nullptr, max_len));
     qk_debug_set_mode(0);
-    CK(qk_accum_submit_device(acc, d_seq, d_qual, d_off, n_reads, total, max_len, nullptr));
+    CK(submit(acc));
     std::vector<qk_base_info> got(max_len);
     uint64_t ml, nr;
     CK(qk_accum_finish(acc, got.data(), max_len, &ml, &nr));
@@ -254,7 +268,7 @@ int main(int argc, char **argv) {
     auto t0 = std::chrono::steady_clock::now();
     for (uint64_t r = 0; r < n_reads; ++r) {
       const uint8_t *s = &seq[off[r]], *q = &qual[off[r]];
-      uint32_t l = (uint32_t)(off[r + 1] - off[r]);
+      uint32_t l = lens[r];
       for (uint32_t i = 0; i < l; ++i) {
         want[i].content[base_code(s[i])]++;
         unsigned b = q[i] & 127u;
@@ -341,7 +355,7 @@ int main(int argc, char **argv) {
       {1024, 1, 0, 2}, {512, 1, 0, 4}, {512, 1, 0, 2} /* 22-24 */,
   };
   const int modes_fixed[] = {0, 1, 2, 3};
-  const double alg_bytes = 2.0 * total + (ragged ? 8.0 * n_reads : 0.0);
+  const double alg_bytes = 2.0 * n_bases + (ragged ? (gapped ? 12.0 : 8.0) * n_reads : 0.0);
   for (size_t ci = 0; ci < cfgs.size(); ++ci) {
     const Cfg &c = cfgs[ci];
     if (only_cfg >= 0 && (int)ci != only_cfg) continue;
@@ -352,7 +366,7 @@ int main(int argc, char **argv) {
       CK(qk_accum_create(&acc, 0, adapters ? bits.data() : nullptr, max_len));
       CK(qk_accum_configure(acc, c.T, c.U, c.tile, c.wgs));
       qk_debug_set_mode(mode);
-      int rc = qk_accum_submit_device(acc, d_seq, d_qual, d_off, n_reads, total, max_len, nullptr);
+      int rc = submit(acc);
       if (rc) {
         printf("T=%4d U=%d tile=%3d wgs=%d mode=%d : skipped (%s)\n", c.T, c.U, c.tile, c.wgs, mode, qk_last_error());
         qk_accum_destroy(acc);
@@ -360,13 +374,13 @@ int main(int argc, char **argv) {
       }
       // warm up for ~100 ms so the clocks have ramped before anything is timed
       for (int i = 0; i < (int)(0.1 / (total * 4e-13)) + 2; ++i)
-        CK(qk_accum_submit_device(acc, d_seq, d_qual, d_off, n_reads, total, max_len, nullptr));
+        CK(submit(acc));
       CK(qk_accum_sync(acc));
       CK(qk_accum_timing_enable(acc, 1));
       const int iters = 20;
       auto t0 = std::chrono::steady_clock::now();
       for (int i = 0; i < iters; ++i)
-        CK(qk_accum_submit_device(acc, d_seq, d_qual, d_off, n_reads, total, max_len, nullptr));
+        CK(submit(acc));
       CK(qk_accum_sync(acc));
       double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / iters;
       double ms;
@@ -375,7 +389,7 @@ int main(int argc, char **argv) {
       double k = ms / launches * 1e-3;
       printf("T=%4d U=%d tile=%3d wgs=%d mode=%d : hist kernel %.3f ms  %.2f TB/s (%.1f%% of 8)  %.1f Gbases/s | wall/step %.3f ms\n",
              c.T, c.U, c.tile, c.wgs, mode, k * 1e3, alg_bytes / k / 1e12, alg_bytes / k / 8e12 * 100,
-             total / k / 1e9, wall * 1e3);
+             n_bases / k / 1e9, wall * 1e3);
       fflush(stdout);
       qk_accum_destroy(acc);
     }
