@@ -11,14 +11,18 @@
  * resumable at any output position (a match may be cut by the end of a block).
  *
  * Scope: gzip members (any number, concatenated), all three block types.
- * The trailer's ISIZE is checked; the CRC-32 is not (the reference does not
- * surface zlib's CRC errors either: a failing gzread just ends its read loop,
- * quack.c:193).  Anything this decoder rejects makes the caller stop exactly
- * there, like a failing gzread.  tests/test_inflate.py fuzzes it against zlib.
+ * Member trailers (CRC-32, ISIZE) are logged for the caller, which owns the
+ * bytes of a member even when several decoders produced them: source.c chains
+ * the CRCs of the pieces and ends the stream where zlib's gzread — the
+ * reference's reader, quack.c:187,193 — would.  Anything else this decoder
+ * rejects makes the caller stop exactly there, like a failing gzread.
+ * tests/test_inflate.py fuzzes it against zlib.
  */
 #include "inflate_fast.h"
 
+#include <stdlib.h>
 #include <string.h>
+#include <zlib.h>   /* crc32() only */
 
 #define LITLEN_BITS 11
 #define DIST_BITS 8
@@ -366,3 +370,45 @@ uint64_t qkh_inflate_bitpos(const qkh_inflate *z) {
 #undef OUT_T
 #undef READ_FN
 #undef COPY_FN
+
+/* ------------------------------------------------------------ member ends */
+int qkh_end_list_take(qkh_end_list *l, const qkh_inflate *z, size_t before) {
+  for (unsigned i = 0; i < z->tl_n; i++) {
+    if (l->n == l->cap) {
+      const unsigned cap = l->cap ? l->cap * 2 : 8;
+      qkh_member_end *ne = realloc(l->ends, cap * sizeof *ne);
+      if (ne) l->ends = ne;
+      uint32_t *nc = realloc(l->piece_crc, ((size_t)cap + 1) * sizeof *nc);
+      if (nc) l->piece_crc = nc;
+      if (!ne || !nc) return -1;
+      l->cap = cap;
+    }
+    l->ends[l->n] = z->tl[i];
+    l->ends[l->n++].off += before;
+  }
+  return 0;
+}
+
+int qkh_end_list_crcs(qkh_end_list *l, const uint8_t *data, size_t len) {
+  size_t from = 0;
+  if (!l->piece_crc && !(l->piece_crc = malloc(sizeof *l->piece_crc))) return -1;
+  for (unsigned i = 0; i <= l->n; i++) {
+    size_t to = i < l->n ? l->ends[i].off : len;
+    uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
+    if (to > len) to = len;
+    for (size_t at = from; at < to;) {   /* (crc32 takes a 32-bit length) */
+      const size_t step = to - at > ((size_t)1 << 30) ? ((size_t)1 << 30) : to - at;
+      c = (uint32_t)crc32(c, data + at, (uInt)step);
+      at += step;
+    }
+    l->piece_crc[i] = c;
+    from = to;
+  }
+  return 0;
+}
+
+void qkh_end_list_free(qkh_end_list *l) {
+  free(l->ends);
+  free(l->piece_crc);
+  memset(l, 0, sizeof *l);
+}

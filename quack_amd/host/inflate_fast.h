@@ -8,6 +8,19 @@
 enum { QKH_LITLEN_TABLE = 2048 + 4096, QKH_DIST_TABLE = 256 + 2048 };
 enum { QKH_Z_MEMBER, QKH_Z_BLOCK, QKH_Z_STORED, QKH_Z_CODES, QKH_Z_TRAILER, QKH_Z_DONE, QKH_Z_ERROR };
 
+/* A member trailer met while decoding: `off` output elements into the CALL that met it
+ * (the caller adds what it had before), the CRC-32 stored in the file, and whether the
+ * stored length disagreed with the bytes produced.  The decoder checks neither against
+ * the data: the bytes of a member may come from several decoders (pinflate.c), so the
+ * caller chains the CRCs of the pieces (source.c) — zlib's gzread, which the reference
+ * reads through, fails at such a trailer (quack.c:187,193). */
+typedef struct {
+  size_t off;
+  uint32_t crc;
+  uint32_t bad_length;
+} qkh_member_end;
+enum { QKH_TRAILER_LOG = 64 };
+
 typedef struct {
   const uint8_t *in, *in_end;   /* the whole compressed file (memory mapped) */
   uint64_t bitbuf;
@@ -25,10 +38,26 @@ typedef struct {
   int pend_set;                 /* the first trailer met in that state: its ISIZE and the */
   uint32_t pend_isize;          /*   bytes this decoder had produced for the member by then */
   size_t pend_out;
+  /* trailers met by the current call (the caller clears tl_n before a call; a full log ends the call) */
+  unsigned tl_n;
+  qkh_member_end tl[QKH_TRAILER_LOG];
   const uint32_t *litlen, *dist;
   uint32_t fixed_litlen[QKH_LITLEN_TABLE], fixed_dist[QKH_DIST_TABLE];
   uint32_t dyn_litlen[QKH_LITLEN_TABLE], dyn_dist[QKH_DIST_TABLE];
 } qkh_inflate;
+
+/* The member ends of one delivered chunk of output (a ring block, a pinflate slice) and the
+ * CRC-32 of the n + 1 pieces they cut the chunk into. */
+typedef struct {
+  qkh_member_end *ends;
+  uint32_t *piece_crc;
+  unsigned n, cap;
+} qkh_end_list;
+/* append the trailers the last decoder call logged; `before` = chunk bytes produced before that call */
+int qkh_end_list_take(qkh_end_list *l, const qkh_inflate *z, size_t before);
+/* fill piece_crc[0..n] from the chunk's final bytes */
+int qkh_end_list_crcs(qkh_end_list *l, const uint8_t *data, size_t len);
+void qkh_end_list_free(qkh_end_list *l);
 
 void qkh_inflate_init(qkh_inflate *z, const uint8_t *data, size_t len);
 

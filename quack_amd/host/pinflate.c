@@ -35,7 +35,6 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
-
 #include "inflate_fast.h"
 
 enum { WIN = 32768, MAX_THREADS = 32 };
@@ -51,6 +50,9 @@ typedef struct {
   size_t cap8;
   size_t len;      /* output bytes of the slice, at b8 + WIN */
   int ready;
+  /* member trailers inside the slice and the CRC-32 of the pieces they cut it into, computed by
+   * the worker once the bytes are final */
+  qkh_end_list el;
 } pslot;
 
 struct qkh_pinflate {
@@ -123,6 +125,7 @@ static void speculate(qkh_pinflate *p, unsigned k, pslot *s, qkh_inflate *z, spe
   for (;;) {
     if (n == s->cap16 && grow16(s, n + 1)) return;
     long got = qkh_inflate_read16(z, s->b16 + WIN + n, s->cap16 - n, WIN + n);
+    if (qkh_end_list_take(&s->el, z, n)) return;
     if (got > 0) n += (size_t)got;
     if (n > SPEC_MAX) return;              /* see SPEC_MAX */
     if (z->state == QKH_Z_ERROR) return;   /* garbage, or a damaged file: decided in order */
@@ -173,6 +176,7 @@ static void *worker_main(void *arg) {
     s = &p->slots[k % p->n_slots];
     s->ready = 0;
     s->len = 0;
+    s->el.n = 0;
     pthread_mutex_unlock(&p->mu);
 
     memset(&sp, 0, sizeof sp);
@@ -216,6 +220,7 @@ static void *worker_main(void *arg) {
         end = sp.end;
       } else {
         /* in order, from the exact bit the previous slice stopped at */
+        s->el.n = 0;
         if (k == 0) qkh_inflate_init(z, p->in, p->in_len);
         else qkh_inflate_init_at(z, p->in, p->in_len, p->chain_bit, p->chain_member_out, p->chain_members, 0);
         z->stop_bit = k + 1 < p->n_slices ? slice_bit(p, k + 1) : 0;
@@ -227,6 +232,7 @@ static void *worker_main(void *arg) {
             break;
           }
           long got = qkh_inflate_read(z, s->b8 + WIN + n, s->cap8 - n, p->chain_win_len + n);
+          if (qkh_end_list_take(&s->el, z, n)) failed = 1;
           if (got > 0) n += (size_t)got;
           if (z->stopped || z->state == QKH_Z_DONE || z->state == QKH_Z_ERROR || got <= 0) break;
         }
@@ -238,6 +244,7 @@ static void *worker_main(void *arg) {
           new_win_len = p->chain_win_len + n < WIN ? p->chain_win_len + n : WIN;
           memcpy(new_win, s->b8 + WIN + n - new_win_len, new_win_len);
         }
+        if (!failed && qkh_end_list_crcs(&s->el, s->b8 + WIN, n)) failed = 1;
       }
     }
 
@@ -264,8 +271,10 @@ static void *worker_main(void *arg) {
     if (keep) {
       /* the bulk of the work, off the chain: lut still holds the previous window */
       resolve(s->b16 + WIN, s->b8 + WIN, n, lut);
+      const int crc_failed = qkh_end_list_crcs(&s->el, s->b8 + WIN, n);
       pthread_mutex_lock(&p->mu);
-      s->len = n;
+      if (crc_failed) p->failed = 1;
+      s->len = crc_failed ? 0 : n;
       s->ready = 1;
       pthread_cond_broadcast(&p->cv);
       pthread_mutex_unlock(&p->mu);
@@ -347,8 +356,15 @@ int qkh_pinflate_next(qkh_pinflate *p, const uint8_t **data, size_t *len) {
     *len = s->len;
     p->holding = 1;
     pthread_mutex_unlock(&p->mu);
-    if (*len) return 1;
+    if (*len || s->el.n) return 1;   /* (a slice may hold nothing but a member's trailer) */
   }
+}
+
+void qkh_pinflate_ends(qkh_pinflate *p, const qkh_member_end **ends, unsigned *n_ends, const uint32_t **piece_crc) {
+  const pslot *s = &p->slots[p->tail % p->n_slots];   /* the slice handed out by the last qkh_pinflate_next */
+  *ends = s->el.ends;
+  *n_ends = p->holding ? s->el.n : 0;
+  *piece_crc = s->el.piece_crc;
 }
 
 void qkh_pinflate_stats(const qkh_pinflate *p, unsigned *kept, unsigned *redone) {
@@ -369,6 +385,7 @@ void qkh_pinflate_close(qkh_pinflate *p) {
     for (unsigned i = 0; i < p->n_slots; i++) {
       free(p->slots[i].b16);
       free(p->slots[i].b8);
+      qkh_end_list_free(&p->slots[i].el);
     }
   free(p->slots);
   free(p);

@@ -5,12 +5,18 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "inflate_fast.h"
+
 typedef struct qkh_pinflate qkh_pinflate;
 
 /* `data` (the whole compressed file) must stay mapped until close. */
 qkh_pinflate *qkh_pinflate_open(const uint8_t *data, size_t len, int threads, size_t slice_bytes);
 /* Same contract as qkh_source_next: the decompressed stream, in order, one slice per call. */
 int qkh_pinflate_next(qkh_pinflate *p, const uint8_t **data, size_t *len);
+/* The gzip member trailers inside the slice handed out by the last qkh_pinflate_next (offsets into
+ * it, stored CRC-32 / length verdict), and the CRC-32 of the n_ends + 1 pieces they cut it into:
+ * the caller chains them across slices (crc32_combine) and compares at every member end. */
+void qkh_pinflate_ends(qkh_pinflate *p, const qkh_member_end **ends, unsigned *n_ends, const uint32_t **piece_crc);
 /* slices whose speculative decode was kept / that were decoded again in order */
 void qkh_pinflate_stats(const qkh_pinflate *p, unsigned *kept, unsigned *redone);
 void qkh_pinflate_close(qkh_pinflate *p);

@@ -22,6 +22,20 @@
  *
  * Whatever a producer cannot decode ends the stream at that byte — the
  * reference's read loop also just stops when gzread fails (quack.c:193).
+ *
+ * Member trailers.  The own decoders log the trailers they meet and the
+ * producers compute the CRC-32 of the pieces between them (on their threads);
+ * qkh_source_next chains the pieces (crc32_combine) and compares at every member
+ * end.  On a mismatch (CRC or length) the stream ends where the REFERENCE's
+ * would.  The reference reads through kseq, i.e. gzread(fp, buf, 16384) calls,
+ * and zlib's gzread returns nothing at all from the call in which inflate meets
+ * a bad trailer — so the stream ends at the START of that call, a multiple of
+ * 16384 (goldens of the reference binary: tests/golden/svg/badcrc_*).  Which
+ * call that is takes a small model of gzread (gzread_model below): after a
+ * member boundary zlib decodes up to 16 KiB AHEAD into its own buffer, so the
+ * bad trailer can be met up to 32 KiB of output before the caller gets there.
+ * To be able to take those bytes back, the last 32 KiB of every chunk are
+ * handed out together with the next chunk.
  */
 #include "source.h"
 
@@ -38,7 +52,57 @@
 #include "inflate_fast.h"
 #include "pinflate.h"
 
-enum { BLOCK_BYTES = 4 << 20, HIST = 32768, SERIAL_RING = 4, MAX_WORKERS = 32 };
+enum { BLOCK_BYTES = 4 << 20, HIST = 32768, SERIAL_RING = 4, MAX_WORKERS = 32, GZREAD_CHUNK = 16384,
+       HOLD_BACK = 2 * GZREAD_CHUNK };
+
+/* zlib's gzread (1.2.x, gzread.c: gz_read / gz_fetch / gz_decomp) under kseq's fixed 16384-byte calls,
+ * as far as it decides WHERE a stream with a damaged member ends.  Offsets are absolute output bytes.
+ *   call_start  where the current gzread call began (every completed call returned 16384 bytes)
+ *   cpos        what the current call has been given so far
+ *   dec         how far inflate has decoded: [cpos, dec) sits in zlib's output buffer
+ *   look        the previous member ended: the next step looks for a header and decodes into the buffer
+ * gz_decomp loses the output of the call that fails and gz_read then returns 0 for the whole gzread, so
+ * the reference's stream ends at call_start. */
+typedef struct {
+  uint64_t call_start, cpos, dec;
+  int look;
+} gzread_model;
+
+/* advance the model to the end of the member that ends at absolute offset `end`; if its trailer is bad,
+ * return 1 with *cut = where the reference's stream ends */
+static int gzread_model_member(gzread_model *m, uint64_t end, int bad, uint64_t *cut) {
+  for (;;) {
+    const uint64_t need = m->call_start + GZREAD_CHUNK - m->cpos;   /* > 0 */
+    if (m->dec > m->cpos) {   /* buffered output first */
+      const uint64_t take = m->dec - m->cpos < need ? m->dec - m->cpos : need;
+      m->cpos += take;
+      if (m->cpos == m->call_start + GZREAD_CHUNK) m->call_start = m->cpos;
+      continue;
+    }
+    /* one gz_decomp: into zlib's buffer (2 x 8192) after a member boundary or for a short remainder,
+     * else straight into the caller's 16384 bytes */
+    const int direct = !m->look && need == GZREAD_CHUNK;
+    const uint64_t room = direct ? need : GZREAD_CHUNK;
+    const uint64_t produce = end - m->dec < room ? end - m->dec : room;
+    m->look = 0;
+    m->dec += produce;
+    if (direct) {
+      m->cpos += produce;
+      if (m->cpos == m->call_start + GZREAD_CHUNK && m->dec < end) m->call_start = m->cpos;   /* (at the end: below) */
+    }
+    if (m->dec == end) {
+      /* inflate reached the trailer in this very call — also when the output filled up exactly at the
+       * member's end: the end-of-block code and the trailer need no output room */
+      if (bad) {
+        *cut = m->call_start;
+        return 1;
+      }
+      m->look = 1;
+      if (direct && m->cpos == m->call_start + GZREAD_CHUNK) m->call_start = m->cpos;
+      return 0;
+    }
+  }
+}
 
 typedef struct {
   uint8_t *base;        /* allocation: HIST bytes of history + BLOCK_BYTES of data */
@@ -48,6 +112,7 @@ typedef struct {
   /* bgzf task */
   const uint8_t *in;
   size_t in_len, expect;
+  qkh_end_list el;      /* member ends inside the block, CRC-32 of the pieces between them */
 } block;
 
 struct qkh_source {
@@ -79,6 +144,17 @@ struct qkh_source {
   /* bgzf */
   qkh_inflate *worker_z[MAX_WORKERS];
   int n_workers;
+  /* member CRC chain and the hold-back of qkh_source_next (own decoders only) */
+  int checks;               /* this producer's members are checked here (not zlib / plain) */
+  uint32_t run_crc;         /* CRC-32 of the current member so far */
+  uint64_t run_len;         /* ... and its length */
+  uint64_t delivered_raw;   /* bytes taken from the producers so far (absolute stream offset of the next chunk) */
+  gzread_model model;
+  uint8_t held[HOLD_BACK];
+  size_t n_held;            /* undelivered tail of the previous chunk */
+  const uint8_t *cur;       /* the chunk handed out by the producer layer, and how much of it was given out */
+  size_t cur_len;
+  int crc_ended;            /* a trailer did not match: the stream is over */
 };
 
 /* ------------------------------------------------------------- ring basics */
@@ -94,6 +170,7 @@ static block *claim_block(qkh_source *s) { /* producer side; NULL when closing *
   b->ready = 0;
   b->len = 0;
   b->in = NULL;
+  b->el.n = 0;
   pthread_mutex_unlock(&s->mu);
   return b;
 }
@@ -112,8 +189,13 @@ static size_t fill_serial(qkh_source *s, block *b) {
   if (s->zf) {
     long k = 1;
     memcpy(b->data - s->hist_len, s->hist, s->hist_len);
-    while (got < BLOCK_BYTES && (k = qkh_inflate_read(s->zf, b->data + got, BLOCK_BYTES - got, s->hist_len + got)) > 0)
+    b->el.n = 0;
+    while (got < BLOCK_BYTES && (k = qkh_inflate_read(s->zf, b->data + got, BLOCK_BYTES - got, s->hist_len + got)) > 0) {
+      if (qkh_end_list_take(&b->el, s->zf, got)) return 0;
       got += (size_t)k;
+    }
+    if (k <= 0 && qkh_end_list_take(&b->el, s->zf, got)) return 0;   /* (a trailer met by a call that produced nothing) */
+    if (qkh_end_list_crcs(&b->el, b->data, got)) return 0;
     if (got >= HIST) {
       memcpy(s->hist, b->data + got - HIST, HIST);
       s->hist_len = HIST;
@@ -127,8 +209,10 @@ static size_t fill_serial(qkh_source *s, block *b) {
     long n = 1;
     while (got < BLOCK_BYTES && (n = read(s->fd, b->data + got, BLOCK_BYTES - got)) > 0) got += (size_t)n;
   } else {
-    int n = gzread(s->gz, b->data, BLOCK_BYTES);
-    got = n > 0 ? (size_t)n : 0;
+    /* exactly the reference's calls — gzread(fp, buf, 16384) under kseq (quack.c:152), default gzbuffer —
+     * so that a damaged stream ends at the same byte: zlib drops the output of the call that fails */
+    int n = 1;
+    while (got + GZREAD_CHUNK <= BLOCK_BYTES && (n = gzread(s->gz, b->data + got, GZREAD_CHUNK)) > 0) got += (size_t)n;
   }
   return got;
 }
@@ -251,7 +335,13 @@ static void *bgzf_worker_main(void *arg) {
     b = &s->ring[s->next_work++ % s->n_ring];
     pthread_mutex_unlock(&s->mu);
     qkh_inflate_init(z, b->in, b->in_len);
-    while (got < BLOCK_BYTES && (k = qkh_inflate_read(z, b->data + got, BLOCK_BYTES - got, got)) > 0) got += (size_t)k;
+    b->el.n = 0;
+    while (got < BLOCK_BYTES && (k = qkh_inflate_read(z, b->data + got, BLOCK_BYTES - got, got)) > 0) {
+      if (qkh_end_list_take(&b->el, z, got)) break;
+      got += (size_t)k;
+    }
+    if (k <= 0) (void)qkh_end_list_take(&b->el, z, got);
+    (void)qkh_end_list_crcs(&b->el, b->data, got);
     pthread_mutex_lock(&s->mu);
     b->len = got;   /* != expect marks an undecodable run: the consumer ends the stream after it */
     b->ready = 1;
@@ -290,7 +380,6 @@ qkh_source *qkh_source_open(const char *path) {
    * faster producers */
   s->gz = gzopen(path, "rb");
   if (!s->gz) goto fail;
-  gzbuffer(s->gz, 1 << 20);
   snprintf(s->kind, sizeof s->kind, "zlib");
   if (stat(path, &st) == 0 && S_ISREG(st.st_mode)) {
     int fd = open(path, O_RDONLY);
@@ -318,6 +407,9 @@ qkh_source *qkh_source_open(const char *path) {
           s->pz = qkh_pinflate_open(s->map, s->map_len, n_cpus(), pgzip_slice());
           if (!s->pz) goto fail;
           snprintf(s->kind, sizeof s->kind, "pgzip x%d", n_cpus());
+          s->checks = 1;
+          s->model.look = 1;   /* gzread starts by looking for a header */
+          s->run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
           return s;
         } else {
           s->zf = malloc(sizeof *s->zf);
@@ -331,6 +423,9 @@ qkh_source *qkh_source_open(const char *path) {
       close(fd);
     }
   }
+  s->checks = s->map != NULL;   /* bgzf, inflate_fast (pgzip returned above); zlib checks for itself */
+  s->run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
+  s->model.look = 1;   /* gzread starts by looking for a header */
   s->n_ring = workers ? (unsigned)(2 * workers < SERIAL_RING ? SERIAL_RING : 2 * workers) : SERIAL_RING;
   s->ring = calloc(s->n_ring, sizeof *s->ring);
   if (!s->ring) goto fail;
@@ -368,8 +463,15 @@ fail:
   return NULL;
 }
 
-int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len) {
-  if (s->pz) return qkh_pinflate_next(s->pz, data, len);
+/* the producer layer: next chunk in stream order, with its member ends */
+static int raw_next(qkh_source *s, const uint8_t **data, size_t *len, const qkh_member_end **ends, unsigned *n_ends,
+                    const uint32_t **piece_crc) {
+  *n_ends = 0;
+  if (s->pz) {
+    const int r = qkh_pinflate_next(s->pz, data, len);
+    if (r) qkh_pinflate_ends(s->pz, ends, n_ends, piece_crc);
+    return r;
+  }
   for (;;) {
     block *b;
     pthread_mutex_lock(&s->mu);
@@ -389,10 +491,77 @@ int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len) {
     if (b->in && b->len != b->expect) s->ended = 1;   /* deliver what it produced, then stop */
     *data = b->data;
     *len = b->len;
+    *ends = b->el.ends;
+    *n_ends = b->el.n;
+    *piece_crc = b->el.piece_crc;
     s->holding = 1;
     pthread_mutex_unlock(&s->mu);
+    if (*len || *n_ends) return 1;
+    /* an empty run: take the next one */
+  }
+}
+
+int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len) {
+  const qkh_member_end *ends;
+  const uint32_t *piece;
+  unsigned n_ends;
+  if (!s->checks) return raw_next(s, data, len, &ends, &n_ends, &piece);
+  for (;;) {
+    const uint8_t *raw;
+    size_t raw_len, keep;
+    if (s->crc_ended) return 0;
+    /* the tail of the chunk that is about to be released has not been handed out yet */
+    if (s->cur && s->n_held) memcpy(s->held, s->cur + s->cur_len - s->n_held, s->n_held);
+    s->cur = NULL;
+    if (!raw_next(s, &raw, &raw_len, &ends, &n_ends, &piece)) {
+      /* the stream ended without a complaint: the held bytes are good */
+      if (!s->n_held) return 0;
+      *data = s->held;
+      *len = s->n_held;
+      s->n_held = 0;
+      s->crc_ended = 1;   /* (nothing follows) */
+      return 1;
+    }
+    /* every chunk has >= 32 KiB of headroom in front of its data (ring blocks, pinflate slots) */
+    uint8_t *front = (uint8_t *)raw - s->n_held;
+    memcpy(front, s->held, s->n_held);
+    /* chain the member CRCs through the chunk */
+    size_t from = 0, good = raw_len;
+    int bad = 0;
+    for (unsigned i = 0; i <= n_ends && !bad; i++) {
+      const size_t to = i < n_ends ? (ends[i].off < raw_len ? ends[i].off : raw_len) : raw_len;
+      s->run_crc = (uint32_t)crc32_combine(s->run_crc, piece[i], (z_off_t)(to - from));
+      s->run_len += to - from;
+      if (i < n_ends) {
+        uint64_t cut = 0;
+        if (gzread_model_member(&s->model, s->delivered_raw + to, ends[i].bad_length || ends[i].crc != s->run_crc, &cut)) {
+          /* the reference never sees the bytes from `cut` on (see gzread_model) */
+          const uint64_t have_from = s->delivered_raw - s->n_held;   /* absolute offset of `front` */
+          good = cut > have_from ? (size_t)(cut - have_from) : 0;
+          bad = 1;
+        }
+        s->run_crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        s->run_len = 0;
+      }
+      from = to;
+    }
+    if (bad) {
+      s->crc_ended = 1;
+      s->n_held = 0;
+      if (!good) return 0;
+      *data = front;
+      *len = good;
+      return 1;
+    }
+    s->delivered_raw += raw_len;
+    s->cur = front;
+    s->cur_len = s->n_held + raw_len;
+    keep = s->cur_len < HOLD_BACK ? s->cur_len : HOLD_BACK;
+    *data = front;
+    *len = s->cur_len - keep;
+    s->n_held = keep;
     if (*len) return 1;
-    /* an empty run (e.g. only the BGZF end-of-file marker): take the next one */
+    /* everything is held back: go on */
   }
 }
 
@@ -424,7 +593,10 @@ void qkh_source_close(qkh_source *s) {
   free(s->hist);
   for (int i = 0; i < MAX_WORKERS; i++) free(s->worker_z[i]);
   if (s->ring)
-    for (unsigned i = 0; i < s->n_ring; i++) free(s->ring[i].base);
+    for (unsigned i = 0; i < s->n_ring; i++) {
+      free(s->ring[i].base);
+      qkh_end_list_free(&s->ring[i].el);
+    }
   free(s->ring);
   free(s);
 }

@@ -173,6 +173,28 @@ def main():
     write("single_read.fq", fastq([("only", "ACGTNACGTTGCA", "IIIIIHHHHH###")]))
     write("one_base.fq", fastq([("b%d" % i, "ACGTN"[i % 5], "5") for i in range(20)]))
 
+    # 10. gzip members whose trailer does not match their data (a flipped bit in the stored CRC-32, a wrong
+    #     ISIZE): zlib's gzread fails the 16 KiB read in which inflate meets the trailer, so the reference
+    #     loses the bytes from the last multiple of 16384 on and stops there
+    recs = [("x%d" % i, rand_seq(rng, 100), rand_qual(rng, 100, levels=levels8[3:7])) for i in range(800)]
+    text = fastq(recs)
+    write("good800.fq.gz", text, gz=True)
+    good = open(os.path.join(OUT, "good800.fq.gz"), "rb").read()
+    os.remove(os.path.join(OUT, "good800.fq.gz"))
+    bad = bytearray(good)
+    bad[-6] ^= 0x10                               # CRC-32 field = bytes -8..-5
+    open(os.path.join(OUT, "badcrc800.fq.gz"), "wb").write(bytes(bad))
+    bad = bytearray(good)
+    bad[-4] ^= 0x01                               # ISIZE field = bytes -4..-1
+    open(os.path.join(OUT, "badlen800.fq.gz"), "wb").write(bytes(bad))
+    # two members, the FIRST one damaged: nothing of the second is ever read
+    write("two_members.tmp.gz", text, gz=True, members=2)
+    two = bytearray(open(os.path.join(OUT, "two_members.tmp.gz"), "rb").read())
+    os.remove(os.path.join(OUT, "two_members.tmp.gz"))
+    second = two.index(b"\x1f\x8b\x08", 10)      # start of the second member
+    two[second - 7] ^= 0x80
+    open(os.path.join(OUT, "badcrc_first_of_two.fq.gz"), "wb").write(bytes(two))
+
 
 if __name__ == "__main__":
     main()

@@ -107,3 +107,73 @@ def test_equal_length_reads_stay_fixed_length_batches(quack_double, tmp_path):
 def test_a_read_larger_than_a_slot_is_an_error_not_a_truncation(quack_double):
     r = run(quack_double, ["-u", "long40.fq.gz"], QK_DOUBLE_SLOT_BYTES="3000")
     assert r.returncode == 1 and r.stdout == b"" and b"exceeds the batch size" in r.stderr
+
+
+# ---------------------------------------------------------------- damaged gzip trailers (CRC-32 / ISIZE)
+PRODUCERS = {"pgzip": dict(QUACK_PGZIP_CHUNK_KB="4", QUACK_THREADS="4"), "inflate_fast": dict(QUACK_NO_PGZIP="1"),
+             "zlib": dict(QUACK_ZLIB="1")}
+
+
+@pytest.mark.parametrize("producer", sorted(PRODUCERS))
+@pytest.mark.parametrize("name", ["badcrc800", "badlen800", "badcrc_first_of_two"])
+def test_a_member_whose_trailer_does_not_match_ends_the_stream_like_gzread(quack_double, name, producer):
+    """every producer stops where the reference (zlib's gzread under kseq's 16 KiB reads) stops: at the last
+    multiple of 16384 before the end of the damaged member — the goldens are the reference binary's output"""
+    argv = dict(cases.load())[name]
+    r = run(quack_double, argv, **PRODUCERS[producer])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == cases.golden_svg(name)
+
+
+def bgzf_bytes(data, member=20000):
+    import struct
+    import zlib
+    out = b""
+    for a in list(range(0, len(data), member)) + [len(data)]:      # (+ the empty end-of-file member)
+        piece = data[a:a + member]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(piece) + c.flush()
+        out += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body +
+                struct.pack("<II", zlib.crc32(piece), len(piece)))
+    return out
+
+
+def member_starts(blob):
+    return [i for i in range(len(blob) - 3) if blob[i:i + 4] in (b"\x1f\x8b\x08\x04", b"\x1f\x8b\x08\x00") and
+            (i == 0 or True)]
+
+
+@pytest.mark.parametrize("kind", ["bgzf", "members"])
+def test_damaged_member_in_the_middle_of_many(quack_double, tmp_path, kind):
+    """many members, one of them with a flipped CRC bit, at every slice / block geometry: the own producers
+    (BGZF workers, speculative multi-threaded inflate, serial decoder) deliver exactly what zlib delivers —
+    also when the cut lies in the chunk BEFORE the one that holds the damaged trailer (the 16 KiB hold-back)"""
+    import gzip
+    import io
+    g = np.random.default_rng(31)
+    fq = tmp_path / "many.fq"
+    write_fastq(fq, g.integers(60, 120, 4000), g)
+    text = open(fq, "rb").read()
+    for victim in (3, 9, 17):
+        if kind == "bgzf":
+            blob = bytearray(bgzf_bytes(text, member=16000 + 123 * victim))
+        else:
+            buf = io.BytesIO()
+            step = 5000 + 777 * victim
+            for a in range(0, len(text), step):
+                with gzip.GzipFile(fileobj=buf, mode="wb", mtime=0) as z:
+                    z.write(text[a:a + step])
+            blob = bytearray(buf.getvalue())
+        # flip a bit in the CRC field of member `victim`: 8 bytes before the next member's magic
+        starts = [i for i in range(len(blob) - 10) if blob[i:i + 3] == b"\x1f\x8b\x08" and blob[i + 8] in (0, 2) and blob[i + 9] in (0xff, 3)]
+        assert len(starts) > victim + 1, len(starts)
+        blob[starts[victim + 1] - 7] ^= 0x04
+        path = tmp_path / ("damaged_%s_%d.fq.gz" % (kind, victim))
+        path.write_bytes(bytes(blob))
+        want = run(quack_double, ["-u", str(path)], QUACK_ZLIB="1")
+        assert want.returncode == 0 and len(want.stdout) > 1000
+        for env in (dict(QUACK_PGZIP_CHUNK_KB="4", QUACK_THREADS="5"), dict(QUACK_PGZIP_CHUNK_KB="16", QUACK_THREADS="2"),
+                    dict(QUACK_NO_PGZIP="1", QUACK_NO_BGZF="1"), dict(QUACK_THREADS="3")):
+            got = run(quack_double, ["-u", str(path)], **env)
+            assert got.returncode == 0, got.stderr[-1000:]
+            assert got.stdout == want.stdout, (kind, victim, env)
