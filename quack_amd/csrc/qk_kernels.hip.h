@@ -639,6 +639,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
           hits &= n >= 8u ? 0xFFu : (1u << n) - 1u;
           hits &= cp >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cp)) - 1u));
           const uint64_t stream = ((uint64_t)(e.y & 3u) << 32) | e.x;
+          uint32_t found = kNoHit;
           while (hits) {
             const uint32_t j = (uint32_t)__builtin_ctz(hits);
             hits &= hits - 1u;
@@ -647,10 +648,17 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             const bool in_table = p.bucket_log2 ? bucket_has(lds_buckets, km, p.bucket_mul, p.bucket_log2)
                                                 : ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) != 0;
             if (in_table) {
-              atomicMin(&p.first_hit[rd], cp + j);
+              found = cp + j;
               break;   // later windows of this chunk are later positions
             }
           }
+          // An adapter covers several chunks of its read, and their entries sit next to each other in
+          // the queue in ascending position (lane order of one step): only the first of a run of
+          // confirmed entries of one read goes to memory (13.5M -> ~3M atomics per 10M spliced reads)
+          const uint32_t prev_rd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane_id + 63u) & 63u) << 2), (int)rd);
+          const uint32_t prev_found = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane_id + 63u) & 63u) << 2), (int)found);
+          const bool covered = lane_id != 0 && prev_rd == rd && prev_found <= found;
+          if (found != kNoHit && !covered) atomicMin(&p.first_hit[rd], found);
         }
         cand_n = 0;
       };

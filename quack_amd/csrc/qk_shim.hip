@@ -124,27 +124,29 @@ struct qk_accum {
 
 namespace {
 
-int ensure_slots(qk_accum *a) {
-  if (a->slot[0].h_seq) return QK_OK;
-  const uint64_t mb = (uint64_t)env_int("QUACK_HIP_BATCH_MB", 64);
-  a->cap_bytes = mb << 20;
-  a->cap_reads = a->cap_bytes / 32 + 1024;  // >= one read per 32 bytes
-  for (int i = 0; i < 2; ++i) {
-    Slot &s = a->slot[i];
-    QK_HIP(hipHostMalloc((void **)&s.h_seq, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
-    QK_HIP(hipHostMalloc((void **)&s.h_qual, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
-    QK_HIP(hipHostMalloc((void **)&s.h_off, (a->cap_reads + 1) * sizeof(uint64_t), hipHostMallocDefault));
-    QK_HIP(hipHostMalloc((void **)&s.h_len, a->cap_reads * sizeof(uint32_t), hipHostMallocDefault));
-    QK_HIP(hipMalloc((void **)&s.d_len, a->cap_reads * sizeof(uint32_t)));
-    QK_HIP(hipMalloc((void **)&s.d_seq, a->cap_bytes + QK_TAIL_SLACK));
-    QK_HIP(hipMalloc((void **)&s.d_qual, a->cap_bytes + QK_TAIL_SLACK));
-    QK_HIP(hipMalloc((void **)&s.d_off, (a->cap_reads + 1) * sizeof(uint64_t)));
-    if (a->adapters) QK_HIP(hipMalloc((void **)&s.d_hit, a->cap_reads * sizeof(uint32_t)));
-    QK_HIP(hipMemset(s.d_seq + a->cap_bytes, 0, QK_TAIL_SLACK));
-    QK_HIP(hipMemset(s.d_qual + a->cap_bytes, 0, QK_TAIL_SLACK));
-    QK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    QK_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+// The pinned slot `i` and its device twin, allocated on first use: page-locking 150 MB takes
+// ~40 ms, and the second slot's share of that overlaps the tokenizer filling the first.
+int ensure_slot(qk_accum *a, int i) {
+  Slot &s = a->slot[i];
+  if (s.h_seq) return QK_OK;
+  if (!a->cap_bytes) {
+    const uint64_t mb = (uint64_t)env_int("QUACK_HIP_BATCH_MB", 64);
+    a->cap_bytes = mb << 20;
+    a->cap_reads = a->cap_bytes / 32 + 1024;  // >= one read per 32 bytes
   }
+  QK_HIP(hipHostMalloc((void **)&s.h_seq, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
+  QK_HIP(hipHostMalloc((void **)&s.h_qual, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
+  QK_HIP(hipHostMalloc((void **)&s.h_off, (a->cap_reads + 1) * sizeof(uint64_t), hipHostMallocDefault));
+  QK_HIP(hipHostMalloc((void **)&s.h_len, a->cap_reads * sizeof(uint32_t), hipHostMallocDefault));
+  QK_HIP(hipMalloc((void **)&s.d_len, a->cap_reads * sizeof(uint32_t)));
+  QK_HIP(hipMalloc((void **)&s.d_seq, a->cap_bytes + QK_TAIL_SLACK));
+  QK_HIP(hipMalloc((void **)&s.d_qual, a->cap_bytes + QK_TAIL_SLACK));
+  QK_HIP(hipMalloc((void **)&s.d_off, (a->cap_reads + 1) * sizeof(uint64_t)));
+  if (a->adapters) QK_HIP(hipMalloc((void **)&s.d_hit, a->cap_reads * sizeof(uint32_t)));
+  QK_HIP(hipMemset(s.d_seq + a->cap_bytes, 0, QK_TAIL_SLACK));
+  QK_HIP(hipMemset(s.d_qual + a->cap_bytes, 0, QK_TAIL_SLACK));
+  QK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  QK_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   return QK_OK;
 }
 
@@ -202,7 +204,6 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   const bool want_pipe = a->pipe > 0 ? a->pipe > 1 : (a->unroll <= 0 && !ragged && T == 1024);
   pl->pipe = a->pipe > 0 ? a->pipe : (want_pipe ? 2 : 1);
   pl->unroll = a->unroll > 0 ? a->unroll : ((want_pipe && !ragged) ? (pl->fused_adapters ? 2 : 1) : 4);
-  const uint32_t U = (uint32_t)pl->unroll;
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
   uint32_t single_cap = 576u;
   while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, a->adapters, 0, ragged) > 160 * 1024)
@@ -231,6 +232,12 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   if (pl->aligned) {
     tile_pos = cap / 128 * 128;
     n_tiles = (max_len + tile_pos - 1) / tile_pos;
+    // cache-line tiles of long reads like two reads per lane and step with the next step's loads in
+    // flight (1-20 kb reads: (4,1) 0.657 ms, (2,2) 0.631, (4,2) 0.636, (1,2) 0.651, (2,1) 0.701)
+    if (!a->unroll && !a->pipe) {
+      pl->unroll = 2;
+      pl->pipe = 2;
+    }
   }
   // fixed-length reads of a multiple of 4 bases: every chunk is dword aligned
   // (the batch base is: hipMalloc / pinned slots; submit_device checks it)
@@ -242,7 +249,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   pl->ch = tile_pos / 8;
   pl->halo = (pl->fused_adapters && n_tiles > 1) ? 2u : 0u;   // lanes covering the 16 positions before a tile
   pl->rw = (pl->fused_adapters ? T / 64 * 62 : T) / (pl->ch + pl->halo);
-  const uint64_t step = (uint64_t)pl->rw * U;
+  const uint64_t step = (uint64_t)pl->rw * (uint32_t)pl->unroll;
   // the exact table next to the histogram, if it fits (it never narrows a tile: without it
   // the queued candidates are checked against the global table)
   pl->bucket_log2 = pl->fused_adapters ? a->bucket_log2 : 0;
@@ -321,10 +328,10 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
   } else
   if (aligned && !fixed && mode == 0) {
     // only built for the planner's own choice (make_plan sets `aligned` for nothing else)
-    if constexpr (T == 1024 && U == 4 && PD == 1)
+    if constexpr (T == 1024 && U == 2 && PD == 2)
       k = adapt ? qk::hist_kernel<T, U, false, 0, true, PD, true> : qk::hist_kernel<T, U, false, 0, false, PD, true>;
 #ifdef QK_ABLATION   /* kbench / experiments: other step shapes of the cache-line variant */
-    if constexpr (T == 1024 && ((U == 2 && PD == 2) || (U == 4 && PD == 2) || (U == 1 && PD == 2) || (U == 2 && PD == 1)))
+    if constexpr (T == 1024 && ((U == 4 && PD == 1) || (U == 4 && PD == 2) || (U == 1 && PD == 2) || (U == 2 && PD == 1)))
       if (!adapt) k = qk::hist_kernel<T, U, false, 0, false, PD, true>;
 #endif
   }
@@ -858,7 +865,7 @@ int qk_accum_acquire(qk_accum *a, uint8_t **seq, uint8_t **qual, uint64_t **offs
   if (a->held_slot >= 0) return fail(QK_ESTATE, "a batch is already acquired");
   int rc = set_device(a);
   if (rc) return rc;
-  if ((rc = ensure_slots(a))) return rc;
+  if ((rc = ensure_slot(a, a->next_slot))) return rc;
   Slot &s = a->slot[a->next_slot];
   if (s.busy) {
     QK_HIP(hipEventSynchronize(s.done));

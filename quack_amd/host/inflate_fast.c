@@ -22,7 +22,6 @@
 
 #include <stdlib.h>
 #include <string.h>
-#include <zlib.h>   /* crc32() only */
 
 #define LITLEN_BITS 11
 #define DIST_BITS 8
@@ -394,13 +393,8 @@ int qkh_end_list_crcs(qkh_end_list *l, const uint8_t *data, size_t len) {
   if (!l->piece_crc && !(l->piece_crc = malloc(sizeof *l->piece_crc))) return -1;
   for (unsigned i = 0; i <= l->n; i++) {
     size_t to = i < l->n ? l->ends[i].off : len;
-    uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
     if (to > len) to = len;
-    for (size_t at = from; at < to;) {   /* (crc32 takes a 32-bit length) */
-      const size_t step = to - at > ((size_t)1 << 30) ? ((size_t)1 << 30) : to - at;
-      c = (uint32_t)crc32(c, data + at, (uInt)step);
-      at += step;
-    }
+    const uint32_t c = qkh_crc32(0u, data + from, to - from);
     l->piece_crc[i] = c;
     from = to;
   }
@@ -411,4 +405,26 @@ void qkh_end_list_free(qkh_end_list *l) {
   free(l->ends);
   free(l->piece_crc);
   memset(l, 0, sizeof *l);
+}
+
+/* ------------------------------------------------------------- line index */
+size_t qkh_index_lines(const uint8_t *data, size_t len, uint32_t **nl, size_t *cap) {
+  size_t n = 0;
+  const uint8_t *p = data, *end = data + len;
+  if (len >= 0xFFFFFFFFull) return (size_t)-1;
+  while (p < end) {
+    const uint8_t *q = memchr(p, '\n', (size_t)(end - p));
+    if (!q) break;
+    if (n == *cap) {
+      /* FASTQ: a line per ~75 bytes; grow generously, rarely */
+      size_t c = *cap ? *cap * 2 : (len / 48 + 1024);
+      uint32_t *g = realloc(*nl, c * sizeof *g);
+      if (!g) return (size_t)-1;
+      *nl = g;
+      *cap = c;
+    }
+    (*nl)[n++] = (uint32_t)(q - data);
+    p = q + 1;
+  }
+  return n;
 }

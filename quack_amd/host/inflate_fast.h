@@ -59,6 +59,15 @@ int qkh_end_list_take(qkh_end_list *l, const qkh_inflate *z, size_t before);
 int qkh_end_list_crcs(qkh_end_list *l, const uint8_t *data, size_t len);
 void qkh_end_list_free(qkh_end_list *l);
 
+/* zlib's crc32() with carry-less multiplies where the CPU has them (crc32_fold.c) */
+uint32_t qkh_crc32(uint32_t crc, const uint8_t *buf, size_t len);
+
+/* Offsets of every '\n' in data[0..len) (len < 4 GiB), in a buffer that grows as needed: the
+ * producers index the lines of their chunks on their own threads, so that the tokenizer — one
+ * thread, and the end-to-end limiter — does not have to look for them.  Returns the count, or
+ * (size_t)-1 when there is no index (allocation failure, oversized chunk). */
+size_t qkh_index_lines(const uint8_t *data, size_t len, uint32_t **nl, size_t *cap);
+
 void qkh_inflate_init(qkh_inflate *z, const uint8_t *data, size_t len);
 
 /* Produce up to `cap` bytes at `out`.  The `history` bytes before `out` must be

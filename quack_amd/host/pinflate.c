@@ -53,6 +53,8 @@ typedef struct {
   /* member trailers inside the slice and the CRC-32 of the pieces they cut it into, computed by
    * the worker once the bytes are final */
   qkh_end_list el;
+  uint32_t *nl;    /* offsets of the newlines in the slice (qkh_index_lines), by the worker */
+  size_t n_nl, cap_nl;
 } pslot;
 
 struct qkh_pinflate {
@@ -245,6 +247,7 @@ static void *worker_main(void *arg) {
           memcpy(new_win, s->b8 + WIN + n - new_win_len, new_win_len);
         }
         if (!failed && qkh_end_list_crcs(&s->el, s->b8 + WIN, n)) failed = 1;
+        if (!failed) s->n_nl = qkh_index_lines(s->b8 + WIN, n, &s->nl, &s->cap_nl);
       }
     }
 
@@ -272,6 +275,7 @@ static void *worker_main(void *arg) {
       /* the bulk of the work, off the chain: lut still holds the previous window */
       resolve(s->b16 + WIN, s->b8 + WIN, n, lut);
       const int crc_failed = qkh_end_list_crcs(&s->el, s->b8 + WIN, n);
+      s->n_nl = qkh_index_lines(s->b8 + WIN, n, &s->nl, &s->cap_nl);
       pthread_mutex_lock(&p->mu);
       if (crc_failed) p->failed = 1;
       s->len = crc_failed ? 0 : n;
@@ -367,6 +371,12 @@ void qkh_pinflate_ends(qkh_pinflate *p, const qkh_member_end **ends, unsigned *n
   *piece_crc = s->el.piece_crc;
 }
 
+void qkh_pinflate_lines(qkh_pinflate *p, const uint32_t **nl, size_t *n) {
+  const pslot *s = &p->slots[p->tail % p->n_slots];
+  *nl = s->nl;
+  *n = p->holding ? s->n_nl : (size_t)-1;
+}
+
 void qkh_pinflate_stats(const qkh_pinflate *p, unsigned *kept, unsigned *redone) {
   *kept = p->kept;
   *redone = p->redone;
@@ -386,6 +396,7 @@ void qkh_pinflate_close(qkh_pinflate *p) {
       free(p->slots[i].b16);
       free(p->slots[i].b8);
       qkh_end_list_free(&p->slots[i].el);
+      free(p->slots[i].nl);
     }
   free(p->slots);
   free(p);

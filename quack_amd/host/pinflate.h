@@ -17,6 +17,8 @@ int qkh_pinflate_next(qkh_pinflate *p, const uint8_t **data, size_t *len);
  * it, stored CRC-32 / length verdict), and the CRC-32 of the n_ends + 1 pieces they cut it into:
  * the caller chains them across slices (crc32_combine) and compares at every member end. */
 void qkh_pinflate_ends(qkh_pinflate *p, const qkh_member_end **ends, unsigned *n_ends, const uint32_t **piece_crc);
+/* newline offsets of that slice (n == (size_t)-1: none) */
+void qkh_pinflate_lines(qkh_pinflate *p, const uint32_t **nl, size_t *n);
 /* slices whose speculative decode was kept / that were decoded again in order */
 void qkh_pinflate_stats(const qkh_pinflate *p, unsigned *kept, unsigned *redone);
 void qkh_pinflate_close(qkh_pinflate *p);

@@ -70,18 +70,18 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
   *bases_out = NULL;
   *max_len = *n_reads = 0;
   if (n_devices < 1 || n_devices > 64) return host_fail("bad device count %d", n_devices);
-  for (; made < n_devices; made++)
-    if (qk_accum_create(&accs[made], devices[made], bitset, 0)) {
-      host_fail("device %d: %s", devices[made], qk_last_error());
-      goto out;
-    }
-  /* (opening the reader first, so that inflate overlaps HIP's start-up, was measured:
-   * no gain — the tokenizer, not inflate, paces the file) */
+  /* the reader first: its producer threads inflate (and index) the first slices while the HIP runtime
+   * starts up and the pinned slots are allocated — 0.2-0.3 s in which the tokenizer cannot run yet */
   rd = qkh_reader_open(path);
   if (!rd) {
     host_fail("cannot open %s", path);
     goto out;
   }
+  for (; made < n_devices; made++)
+    if (qk_accum_create(&accs[made], devices[made], bitset, 0)) {
+      host_fail("device %d: %s", devices[made], qk_last_error());
+      goto out;
+    }
   t_created = now_s();
   while (!qkh_reader_done(rd)) {
     uint8_t *seq, *qual;

@@ -39,6 +39,8 @@ struct qkh_reader {
   qkh_source *src;
   const uint8_t *buf;  /* the source block being parsed */
   size_t pos, lim;
+  const uint32_t *nl;  /* the block's newline offsets, indexed by the producer threads (NULL: none) */
+  size_t n_nl, li;     /* ... how many, and the first one not known to lie before pos */
   int have_block;
   int eof;
   int marker;          /* header marker already consumed ('>' / '@'), or 0 */
@@ -52,12 +54,15 @@ struct qkh_reader {
 static int refill(qkh_reader *r) {
   if (r->eof) return 0;
   r->pos = 0;
+  r->nl = NULL;
+  r->n_nl = r->li = 0;
   if (!qkh_source_next(r->src, &r->buf, &r->lim)) {
     r->lim = 0;
     r->eof = 1;
     r->have_block = 0;
     return 0;
   }
+  if (!qkh_source_lines(r->src, &r->nl, &r->n_nl)) r->nl = NULL;
   r->have_block = 1;
   return 1;
 }
@@ -222,6 +227,36 @@ static size_t fast_record(qkh_reader *r, uint8_t *seq_dst, uint8_t *qual_dst, si
   if (!r->have_block || r->pos >= r->lim) return 0;
   p = r->buf + r->pos;
   end = r->buf + r->lim;
+  if (r->nl) {
+    /* The same record shape and the same tests, with the four line ends read off the producers'
+     * index instead of four memchr calls (the tokenizer is one thread and paces the whole file). */
+    const uint32_t *nl = r->nl;
+    size_t li = r->li;
+    while (li < r->n_nl && nl[li] < r->pos) li++;   /* (after the general parser consumed lines) */
+    r->li = li;
+    if (li + 4 > r->n_nl) return 0;
+    if (r->marker) {
+      if (r->marker != '@') return 0;
+    } else if (*p != '@') {
+      return 0;
+    }
+    h = r->buf + nl[li];
+    s0 = h + 1;
+    e1 = r->buf + nl[li + 1];
+    e2 = r->buf + nl[li + 2];
+    q0 = e2 + 1;
+    len = (size_t)(e1 - s0);
+    if (len == 0 || *s0 == '>' || *s0 == '+' || *s0 == '@') return 0;
+    if (e1[-1] == '\r' || e1[1] != '+') return 0;
+    if (r->buf + nl[li + 3] != q0 + len || q0[len - 1] == '\r') return 0;
+    if (len > room) return 0;
+    memcpy(seq_dst, s0, len);
+    memcpy(qual_dst, q0, len);
+    r->pos = (size_t)nl[li + 3] + 1;
+    r->li = li + 4;
+    r->marker = 0;
+    return len;
+  }
   if (r->marker) {
     if (r->marker != '@') return 0;
   } else {

@@ -113,6 +113,8 @@ typedef struct {
   const uint8_t *in;
   size_t in_len, expect;
   qkh_end_list el;      /* member ends inside the block, CRC-32 of the pieces between them */
+  uint32_t *nl;         /* newline offsets of the block (qkh_index_lines), by its producer */
+  size_t n_nl, cap_nl;
 } block;
 
 struct qkh_source {
@@ -155,6 +157,13 @@ struct qkh_source {
   const uint8_t *cur;       /* the chunk handed out by the producer layer, and how much of it was given out */
   size_t cur_len;
   int crc_ended;            /* a trailer did not match: the stream is over */
+  /* line index of the bytes handed out (front .. front + cur_len), offsets relative to `front`:
+   * two buffers, the new one is put together from the tail of the old one and the chunk's own */
+  uint32_t *lines[2];
+  size_t n_lines[2], cap_lines[2];
+  int cur_lines;            /* which of the two describes the current chunk */
+  int have_lines;           /* ... and whether it is complete (every chunk so far came with an index) */
+  size_t given;             /* bytes of the current chunk handed to the caller */
 };
 
 /* ------------------------------------------------------------- ring basics */
@@ -196,6 +205,7 @@ static size_t fill_serial(qkh_source *s, block *b) {
     }
     if (k <= 0 && qkh_end_list_take(&b->el, s->zf, got)) return 0;   /* (a trailer met by a call that produced nothing) */
     if (qkh_end_list_crcs(&b->el, b->data, got)) return 0;
+    b->n_nl = qkh_index_lines(b->data, got, &b->nl, &b->cap_nl);
     if (got >= HIST) {
       memcpy(s->hist, b->data + got - HIST, HIST);
       s->hist_len = HIST;
@@ -342,6 +352,7 @@ static void *bgzf_worker_main(void *arg) {
     }
     if (k <= 0) (void)qkh_end_list_take(&b->el, z, got);
     (void)qkh_end_list_crcs(&b->el, b->data, got);
+    b->n_nl = qkh_index_lines(b->data, got, &b->nl, &b->cap_nl);
     pthread_mutex_lock(&s->mu);
     b->len = got;   /* != expect marks an undecodable run: the consumer ends the stream after it */
     b->ready = 1;
@@ -465,11 +476,15 @@ fail:
 
 /* the producer layer: next chunk in stream order, with its member ends */
 static int raw_next(qkh_source *s, const uint8_t **data, size_t *len, const qkh_member_end **ends, unsigned *n_ends,
-                    const uint32_t **piece_crc) {
+                    const uint32_t **piece_crc, const uint32_t **nl, size_t *n_nl) {
   *n_ends = 0;
+  *n_nl = (size_t)-1;
   if (s->pz) {
     const int r = qkh_pinflate_next(s->pz, data, len);
-    if (r) qkh_pinflate_ends(s->pz, ends, n_ends, piece_crc);
+    if (r) {
+      qkh_pinflate_ends(s->pz, ends, n_ends, piece_crc);
+      qkh_pinflate_lines(s->pz, nl, n_nl);
+    }
     return r;
   }
   for (;;) {
@@ -494,6 +509,8 @@ static int raw_next(qkh_source *s, const uint8_t **data, size_t *len, const qkh_
     *ends = b->el.ends;
     *n_ends = b->el.n;
     *piece_crc = b->el.piece_crc;
+    *nl = b->nl;
+    *n_nl = s->checks ? b->n_nl : (size_t)-1;
     s->holding = 1;
     pthread_mutex_unlock(&s->mu);
     if (*len || *n_ends) return 1;
@@ -503,9 +520,10 @@ static int raw_next(qkh_source *s, const uint8_t **data, size_t *len, const qkh_
 
 int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len) {
   const qkh_member_end *ends;
-  const uint32_t *piece;
+  const uint32_t *piece, *raw_nl;
   unsigned n_ends;
-  if (!s->checks) return raw_next(s, data, len, &ends, &n_ends, &piece);
+  size_t n_raw_nl;
+  if (!s->checks) return raw_next(s, data, len, &ends, &n_ends, &piece, &raw_nl, &n_raw_nl);
   for (;;) {
     const uint8_t *raw;
     size_t raw_len, keep;
@@ -513,14 +531,56 @@ int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len) {
     /* the tail of the chunk that is about to be released has not been handed out yet */
     if (s->cur && s->n_held) memcpy(s->held, s->cur + s->cur_len - s->n_held, s->n_held);
     s->cur = NULL;
-    if (!raw_next(s, &raw, &raw_len, &ends, &n_ends, &piece)) {
+    if (!raw_next(s, &raw, &raw_len, &ends, &n_ends, &piece, &raw_nl, &n_raw_nl)) {
       /* the stream ended without a complaint: the held bytes are good */
       if (!s->n_held) return 0;
       *data = s->held;
       *len = s->n_held;
       s->n_held = 0;
       s->crc_ended = 1;   /* (nothing follows) */
+      s->have_lines = 0;  /* (the tokenizer looks for the last few lines itself) */
       return 1;
+    }
+    /* the line index of front .. front + n_held + raw_len: the held bytes' lines out of the old index,
+     * then the chunk's own */
+    {
+      const int o = s->cur_lines, n = o ^ 1;
+      const size_t old_len = s->cur_len;   /* the old chunk's length; its last n_held bytes are the held ones */
+      size_t cnt = 0;
+      int ok = n_raw_nl != (size_t)-1 && (s->have_lines || s->delivered_raw == 0);
+      if (ok) {
+        size_t from = 0, keep_n = 0;
+        if (s->n_held) {   /* first entry at or behind the held bytes' start (binary search) */
+          size_t lo = 0, hi = s->n_lines[o];
+          const size_t start = old_len - s->n_held;
+          while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (s->lines[o][mid] < start) lo = mid + 1;
+            else hi = mid;
+          }
+          from = lo;
+          keep_n = s->n_lines[o] - lo;
+        }
+        if (keep_n + n_raw_nl > s->cap_lines[n]) {
+          const size_t c = (keep_n + n_raw_nl) * 2 + 1024;
+          uint32_t *g = realloc(s->lines[n], c * sizeof *g);
+          if (g) {
+            s->lines[n] = g;
+            s->cap_lines[n] = c;
+          } else {
+            ok = 0;
+          }
+        }
+        if (ok) {
+          const uint32_t back = (uint32_t)(old_len - s->n_held);
+          for (size_t i = 0; i < keep_n; i++) s->lines[n][i] = s->lines[o][from + i] - back;
+          for (size_t i = 0; i < n_raw_nl; i++) s->lines[n][keep_n + i] = raw_nl[i] + (uint32_t)s->n_held;
+          cnt = keep_n + n_raw_nl;
+        }
+      }
+      s->cur_lines = n;
+      s->n_lines[n] = cnt;
+      s->have_lines = ok;
     }
     /* every chunk has >= 32 KiB of headroom in front of its data (ring blocks, pinflate slots) */
     uint8_t *front = (uint8_t *)raw - s->n_held;
@@ -551,6 +611,7 @@ int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len) {
       if (!good) return 0;
       *data = front;
       *len = good;
+      s->given = good;
       return 1;
     }
     s->delivered_raw += raw_len;
@@ -560,9 +621,25 @@ int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len) {
     *data = front;
     *len = s->cur_len - keep;
     s->n_held = keep;
+    s->given = *len;
     if (*len) return 1;
     /* everything is held back: go on */
   }
+}
+
+int qkh_source_lines(qkh_source *s, const uint32_t **nl, size_t *n) {
+  if (!s->checks || !s->have_lines) return 0;
+  /* the entries inside the bytes handed out (the held-back tail has entries too) */
+  const uint32_t *a = s->lines[s->cur_lines];
+  size_t lo = 0, hi = s->n_lines[s->cur_lines];
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    if (a[mid] < s->given) lo = mid + 1;
+    else hi = mid;
+  }
+  *nl = a;
+  *n = lo;
+  return 1;
 }
 
 const char *qkh_source_kind(const qkh_source *s) { return s->kind; }
@@ -595,8 +672,11 @@ void qkh_source_close(qkh_source *s) {
   if (s->ring)
     for (unsigned i = 0; i < s->n_ring; i++) {
       free(s->ring[i].base);
+      free(s->ring[i].nl);
       qkh_end_list_free(&s->ring[i].el);
     }
   free(s->ring);
+  free(s->lines[0]);
+  free(s->lines[1]);
   free(s);
 }

@@ -12,6 +12,10 @@ qkh_source *qkh_source_open(const char *path);
  * next one, in stream order.  Returns 1 with *data / *len set, or 0 at the end
  * of the stream (EOF or the first undecodable byte, like a failing gzread). */
 int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len);
+/* Offsets of the newlines inside the block handed out by the last qkh_source_next, ascending, relative to
+ * its data pointer — indexed by the producer threads.  Returns 0 when there is no index for this block
+ * (zlib / plain producers, the last few bytes of a stream): the caller looks for the lines itself. */
+int qkh_source_lines(qkh_source *s, const uint32_t **nl, size_t *n);
 void qkh_source_close(qkh_source *s);
 /* "zlib", "inflate_fast", "bgzf xN" or "plain": which producer is running */
 const char *qkh_source_kind(const qkh_source *s);

@@ -50,7 +50,7 @@ def test_the_struct_images_are_the_references(tmp_path):
 @pytest.fixture(scope="module")
 def caller_double(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("dropin") / "dropin_caller_double")
-    src = [CALLER] + [os.path.join(HOST, f) for f in ("dropin.c", "pipeline.c", "reader.c", "source.c", "inflate_fast.c",
+    src = [CALLER] + [os.path.join(HOST, f) for f in ("dropin.c", "pipeline.c", "reader.c", "source.c", "inflate_fast.c", "crc32_fold.c",
                                                       "pinflate.c", "render.c", "cli.c")] + \
           [os.path.join(ROOT, "tests", "c", "cabi_double.c"), os.path.join(ROOT, "oracle", "quack_oracle.c")]
     subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-D_DEFAULT_SOURCE", "-D_POSIX_C_SOURCE=200809L", "-pthread",

@@ -15,7 +15,7 @@ import pytest
 import cases
 
 HOST = os.path.join(cases.ROOT, "quack_amd", "host")
-SRC = [os.path.join(HOST, f) for f in ("main.c", "cli.c", "pipeline.c", "reader.c", "source.c", "inflate_fast.c",
+SRC = [os.path.join(HOST, f) for f in ("main.c", "cli.c", "pipeline.c", "reader.c", "source.c", "inflate_fast.c", "crc32_fold.c",
                                        "pinflate.c", "render.c")] + \
       [os.path.join(cases.ROOT, "tests", "c", "cabi_double.c"), os.path.join(cases.ROOT, "oracle", "quack_oracle.c")]
 

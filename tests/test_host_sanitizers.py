@@ -7,7 +7,7 @@ import subprocess
 import cases
 
 SRC = [os.path.join(cases.ROOT, p) for p in (
-    "tests/c/host_fuzz.c", "quack_amd/host/reader.c", "quack_amd/host/source.c", "quack_amd/host/inflate_fast.c", "quack_amd/host/pinflate.c", "oracle/quack_oracle.c")]
+    "tests/c/host_fuzz.c", "quack_amd/host/reader.c", "quack_amd/host/source.c", "quack_amd/host/inflate_fast.c", "quack_amd/host/crc32_fold.c", "quack_amd/host/pinflate.c", "oracle/quack_oracle.c")]
 
 
 def test_tokenizer_and_inflate_under_asan_ubsan(tmp_path):

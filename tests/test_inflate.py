@@ -321,3 +321,18 @@ def test_parallel_gzip_through_the_tokenizer(tmp_path, monkeypatch):
     a, _ = product_tokenize(str(p), 1 << 22, 1 << 16)
     want, _ = product_tokenize_text(tmp_path, text)
     assert len(a) == 20000 and a == want
+
+
+def test_crc32_fold_is_zlibs_crc32():
+    """the carry-less-multiply CRC-32 of the host feed (crc32_fold.c) against zlib on random lengths,
+    alignments and start values"""
+    H = _capi.host()
+    H.qkh_crc32.restype = ctypes.c_uint32
+    H.qkh_crc32.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+    rng = random.Random(11)
+    blob = bytes(rng.getrandbits(8) for _ in range(70000))
+    for _ in range(3000):
+        a = rng.randrange(0, 100)
+        n = rng.choice([rng.randrange(0, 300), rng.randrange(0, 5000), rng.randrange(0, len(blob) - a)])
+        start = rng.choice([0, rng.getrandbits(32)])
+        assert H.qkh_crc32(start, blob[a:a + n], n) == zlib.crc32(blob[a:a + n], start)

@@ -3,7 +3,7 @@
 # would not pick by itself (small tiles -> everything multi-tile, other
 # workgroup sizes, forced pipelining, separate adapter kernels, 1 MiB slots).
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
-K="not cli and not launch_configurations and not pipelined"
+K="not cli and not launch_configurations and not pipelined and not strided and not stride"
 for e in "QUACK_HIP_TILE=64" "QUACK_HIP_THREADS=512" "QUACK_HIP_TILE=128 QUACK_HIP_THREADS=256 QUACK_HIP_UNROLL=2" \
          "QUACK_HIP_PIPE=2 QUACK_HIP_UNROLL=2" "QUACK_HIP_UNFUSED_ADAPTERS=1"; do
   echo "== $e"

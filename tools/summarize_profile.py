@@ -4,6 +4,8 @@ committed under profiles/:  <tag>_kernel_stats.csv, <tag>_pmc.json,
 <tag>_summary.md, and the per-workload entry of profiles/hbm_traffic.json that
 bench.py reports as roofline.traffic.
 
+Usage: tools/summarize_profile.py <tag> <workload> <algorithmic bytes per launch> <bases per launch> [kernel]
+
 HBM traffic per launch = 2 * FETCH_SIZE + WRITE_SIZE   (KB -> bytes)
   - FETCH_SIZE / WRITE_SIZE come from separate --pmc passes (TCC slots);
   - gfx950 tallies the 128-B requests of a coalesced stream at 64 B, so
@@ -32,8 +34,8 @@ def counters(d, kern):
 
 
 def main():
-    tag, workload, alg_bytes = sys.argv[1], sys.argv[2], float(sys.argv[3])
-    kern = sys.argv[4] if len(sys.argv) > 4 else "hist_kernel"
+    tag, workload, alg_bytes, bases = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4])
+    kern = sys.argv[5] if len(sys.argv) > 5 else "hist_kernel"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -54,6 +56,29 @@ def main():
         a, b = counters(os.path.join(src, sub), kern)
         pmc.update(a)
         cnt.update(b)
+    # SQ passes: instruction mix per wave and 8-position chunk (a lane owns 8 positions of a read per step),
+    # VALU / LDS-issue load of the SIMDs, LDS bank conflicts
+    sq = {}
+    for sub in ("sq1", "sq2", "sq3"):
+        a, _ = counters(os.path.join(src, sub), kern)
+        sq.update(a)
+    sq_derived = {}
+    if sq.get("SQ_INSTS_VALU"):
+        wave_chunks = bases / 8.0 / 64.0
+        # SQ_BUSY_CYCLES sums the 32 shader engines (measured: 32 x kernel cycles); a wave64 VALU
+        # instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs
+        cycles = sq.get("SQ_BUSY_CYCLES", 0) / 32.0
+        sq_derived = {
+            "valu_insts_per_wave_chunk": sq["SQ_INSTS_VALU"] / wave_chunks,
+            "salu_insts_per_wave_chunk": sq.get("SQ_INSTS_SALU", 0) / wave_chunks,
+            "lds_insts_per_wave_chunk": sq.get("SQ_INSTS_LDS", 0) / wave_chunks,
+            "vmem_rd_insts_per_wave_chunk": sq.get("SQ_INSTS_VMEM_RD", 0) / wave_chunks,
+            "kernel_cycles": cycles,
+            "clock_GHz_implied": cycles / float(k["AverageNs"]) if cycles else None,
+            "valu_busy_share_of_simd_cycles": (sq["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cycles) if cycles else None,
+            "lds_bank_conflict_share": (sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]) if sq.get("SQ_LDS_IDX_ACTIVE") else None,
+            "wait_inst_any_over_wave_cycles": (sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAIT_INST_ANY") else None,
+        }
     calib, _ = counters(os.path.join(src, "pmc_calib"), kern)
     fetch_b = pmc.get("FETCH_SIZE", 0) * 1024
     write_b = pmc.get("WRITE_SIZE", 0) * 1024
@@ -62,7 +87,8 @@ def main():
             "avg_ns": float(k["AverageNs"]), "min_ns": float(k["MinNs"]), "max_ns": float(k["MaxNs"]),
             "algorithmic_bytes_per_launch": alg_bytes, "pmc_per_launch": pmc, "pmc_samples": cnt,
             "hbm_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / alg_bytes,
-            "achieved_GBs_from_trace": alg_bytes / float(k["AverageNs"])}
+            "achieved_GBs_from_trace": alg_bytes / float(k["AverageNs"]),
+            "sq_per_launch": sq, "sq_derived": sq_derived}
     if calib:
         info["calibration_loads_only_FETCH_SIZE_KB"] = calib.get("FETCH_SIZE")
         info["calibration_factor_for_8B_per_lane"] = alg_bytes / (calib["FETCH_SIZE"] * 1024)
@@ -85,6 +111,15 @@ def main():
                    pmc.get("TCC_EA0_ATOMIC_sum", 0)))
         f.write("HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE = %.3f GB = %.3f x algorithmic (%.3f GB)\n"
                 % (traffic / 1e9, traffic / alg_bytes, alg_bytes / 1e9))
+        if sq_derived:
+            d = sq_derived
+            f.write("\nSQ counters (separate passes): %.1f VALU, %.1f SALU, %.1f LDS, %.2f VMEM-read instructions per wave and "
+                    "8-position chunk; VALU busy %.0f %% of the SIMD cycles (%.0f kernel cycles = %.2f GHz); LDS bank-conflict "
+                    "share %.0f %%; waves waiting to issue %.0f %% of their cycles\n"
+                    % (d["valu_insts_per_wave_chunk"], d["salu_insts_per_wave_chunk"], d["lds_insts_per_wave_chunk"],
+                       d["vmem_rd_insts_per_wave_chunk"], 100 * (d["valu_busy_share_of_simd_cycles"] or 0), d["kernel_cycles"],
+                       d["clock_GHz_implied"] or 0, 100 * (d["lds_bank_conflict_share"] or 0),
+                       100 * (d["wait_inst_any_over_wave_cycles"] or 0)))
         if calib:
             f.write("\nCalibration (loads-only build, every byte read once, same 8 B/lane pattern): FETCH_SIZE %.0f KB "
                     "=> factor %.3f (the guide's 2.0 is for 16 B/lane)\n"
