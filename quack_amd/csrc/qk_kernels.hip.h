@@ -92,6 +92,10 @@ struct HistParams {
   uint32_t reads_per_iter;      // chunk lanes per workgroup / ch
   uint32_t n_slices;            // read slices per tile; work items = n_tiles * n_slices
   uint32_t *queue;              // [n_tiles] slice counters (several tiles), or NULL
+  // several tiles and the work of every tile known (reads sorted by reach): no queue — workgroup b
+  // takes the b-th of gridDim.x equal, contiguous shares of the read-tiles
+  const unsigned long long *tile_prefix;   // [n_tiles + 1] reads of the tiles before t, or NULL (t * n_reads)
+  uint32_t static_split;
   uint32_t no_adapters;         // kmers == NULL semantics (quack.c:210,215)
   // exact LDS-resident membership table the queued candidates are checked against (0: the
   // global 2^20-bit table — huge adapter files, or no room): 2^bucket_log2 buckets of eight
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   };
 
   // ---- one work item: reads [r_begin, r_end) x positions of `tile`
-  auto process = [&](uint32_t tile, uint32_t slice) {
+  auto process = [&](uint32_t tile, uint64_t r_begin, uint64_t r_end_in) {
     const uint32_t P0 = tile * p.tile_pos;
     // first position of the owned chunk; halo lanes of tile 0 would sit before
     // the read and are parked beyond any read instead (they then never load)
@@ -426,8 +430,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
     const uint32_t cpos = cpos_s < 0 ? 0xFFFFFF00u : (uint32_t)cpos_s;
     const bool sorted = !FIXED && p.order != nullptr;
     const uint64_t list_len = sorted ? p.reach[tile] : p.n_reads;   // reads this tile has to look at
-    const uint64_t r_begin = (uint64_t)slice * p.reads_per_slice;
-    uint64_t r_end = r_begin + p.reads_per_slice;
+    uint64_t r_end = r_end_in;
     if (r_end > list_len) r_end = list_len;
     const uint32_t slice_reads = r_end > r_begin ? (uint32_t)(r_end - r_begin) : 0u;
     if (FIXED && tile == 0) fixed_reads += slice_reads;
@@ -859,9 +862,9 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   // ---- work loop
   uint32_t cur_tile = 0xFFFFFFFFu, reads_in_tile = 0;
   auto tile_reads = [&](uint32_t tile) -> uint64_t { return (!FIXED && p.reach) ? p.reach[tile] : p.n_reads; };
-  auto run_item = [&](uint32_t tile, uint32_t slice) {
-    const uint64_t rb = (uint64_t)slice * p.reads_per_slice, nt = tile_reads(tile);
-    const uint64_t re = rb + p.reads_per_slice < nt ? rb + p.reads_per_slice : nt;
+  auto run_item = [&](uint32_t tile, uint64_t rb, uint64_t re_in) {
+    const uint64_t nt = tile_reads(tile);
+    const uint64_t re = re_in < nt ? re_in : nt;
     const uint32_t upcoming = re > rb ? (uint32_t)(re - rb) : 0u;
     if (tile != cur_tile || reads_in_tile + upcoming > kMaxReadsPerSlice) {
       if (cur_tile != 0xFFFFFFFFu) {
@@ -873,11 +876,41 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
       cur_tile = tile;
       reads_in_tile = 0;
     }
-    reads_in_tile += process(tile, slice);
+    reads_in_tile += process(tile, rb, re);
   };
+  if (p.static_split) {
+    // Several tiles, work known: the read-tiles (tile 0's reads, then tile 1's, ...) are cut into
+    // gridDim.x equal shares; a share is a contiguous read range in one tile, sometimes the tail of
+    // one and the head of the next — one or two histograms to flush, no queue, no atomics, and as
+    // few items as there can be (per-item costs — staging latency, barriers, the flush — were a
+    // tenth of the long-read kernel: 1-20 kb reads 0.63 -> 0.55 ms).
+    auto prefix = [&](uint32_t t) -> uint64_t { return p.tile_prefix ? p.tile_prefix[t] : (uint64_t)t * p.n_reads; };
+    const uint64_t W = prefix(p.n_tiles);
+    uint64_t lo = W / gridDim.x * blockIdx.x + (W % gridDim.x) * blockIdx.x / gridDim.x;
+    const uint64_t hi = blockIdx.x + 1u == gridDim.x ? W : W / gridDim.x * (blockIdx.x + 1u) + (W % gridDim.x) * (blockIdx.x + 1u) / gridDim.x;
+    // the tile that holds read-tile `lo`: the last t with prefix(t) <= lo
+    uint32_t ta = 0, tb = p.n_tiles;   // invariant: prefix(ta) <= lo < prefix(tb) (when lo < W)
+    while (tb - ta > 1u) {
+      const uint32_t mid = (ta + tb) / 2u;
+      if (prefix(mid) <= lo) ta = mid;
+      else tb = mid;
+    }
+    for (uint32_t t = ta; lo < hi && t < p.n_tiles; ++t) {
+      const uint64_t t0 = prefix(t), t1 = prefix(t + 1u);
+      const uint64_t seg_hi = hi < t1 ? hi : t1;
+      if (seg_hi > lo) {
+        // (items of at most reads_per_slice reads: the u16 counters of a histogram)
+        for (uint64_t r = lo - t0; r < seg_hi - t0; r += p.reads_per_slice) {
+          const uint64_t e = r + p.reads_per_slice < seg_hi - t0 ? r + p.reads_per_slice : seg_hi - t0;
+          run_item(t, r, e);
+        }
+        lo = seg_hi;
+      }
+    }
+  } else
   if (p.queue == nullptr) {
     // one tile: block b owns read slice b
-    if (blockIdx.x < p.n_slices) run_item(0, blockIdx.x);
+    if (blockIdx.x < p.n_slices) run_item(0, (uint64_t)blockIdx.x * p.reads_per_slice, (uint64_t)(blockIdx.x + 1u) * p.reads_per_slice);
   } else {
     // several tiles: one queue of read slices per tile.  The workgroups start
     // spread over all tiles (so that a read's tiles are consumed at about the
@@ -934,7 +967,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
       __syncthreads();
       const uint32_t slice = lds_misc[1];
       if ((uint64_t)slice * p.reads_per_slice >= tile_reads(tile)) continue;   // somebody else got the last one
-      run_item(tile, slice);
+      run_item(tile, (uint64_t)slice * p.reads_per_slice, (uint64_t)(slice + 1u) * p.reads_per_slice);
     }
   }
   if (MODE == 1) {
@@ -998,7 +1031,7 @@ __device__ __forceinline__ void wave_count_global(unsigned long long *row, uint3
 //   reach[t]  = reads in buckets > t
 //   cursor[k] = first slot of bucket k in order[] (longest reads first)
 __global__ __launch_bounds__(kReachThreads) void reach_count_kernel(const HistParams p, uint32_t *counts, uint32_t *done,
-                                                                    uint32_t *reach, uint32_t *cursor) {
+                                                                    uint32_t *reach, uint32_t *cursor, unsigned long long *prefix) {
   extern __shared__ uint32_t lc[];   // n_tiles + 1 counters, + 1 word for the ticket
   __shared__ uint32_t len_cnt[kLenLds];   // ... and the batch's length_count on the way (ragged_length_kernel's job)
   __shared__ uint32_t gt10;
@@ -1049,6 +1082,14 @@ __global__ __launch_bounds__(kReachThreads) void reach_count_kernel(const HistPa
   for (uint32_t t = threadIdx.x; t < p.n_tiles; t += kReachThreads) {
     reach[t] = lc[t];                        // reads in buckets > t
     cursor[t + 1u] = lc[t + 1u];
+  }
+  if (threadIdx.x == 0) {                    // prefix[t] = read-tiles of the tiles before t (hist_kernel's static split)
+    unsigned long long acc = 0;
+    for (uint32_t t = 0; t < p.n_tiles; ++t) {
+      prefix[t] = acc;
+      acc += lc[t];
+    }
+    prefix[p.n_tiles] = acc;
   }
 }
 

@@ -280,7 +280,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // workgroup flushes its LDS histogram only when its tile changes.
   const uint64_t resident = (uint64_t)a->n_cu * wgs;
   pl->dynamic = n_tiles > 1;
-  uint64_t want_items = pl->dynamic ? resident * 16 : resident;
+  uint64_t want_items = pl->dynamic ? resident * (uint64_t)std::max(1, env_int("QUACK_HIP_OVERSUB", 16)) : resident;
   uint64_t n_slices = std::max<uint64_t>(1, want_items / n_tiles);
   uint64_t rps = (n_reads + n_slices - 1) / n_slices;
   rps = round_up(std::max<uint64_t>(rps, 1), step);
@@ -516,21 +516,33 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
       QK_HIP(hipMalloc((void **)&a->d_order, n_reads * sizeof(uint32_t)));
       a->order_cap = n_reads;
     }
-    const size_t reach_words = 3 * (size_t)qk::kReachMaxTiles + 4;   // reach | counts | cursor | done
+    // reach | counts | cursor | done | prefix (u64, 8-byte aligned: the word count before it is even)
+    const size_t reach_words = 3 * (size_t)qk::kReachMaxTiles + 4 + 2 * ((size_t)qk::kReachMaxTiles + 1);
     if (!a->d_reach) {
       QK_HIP(hipMalloc((void **)&a->d_reach, reach_words * sizeof(uint32_t)));
       QK_HIP(hipMemsetAsync(a->d_reach, 0, reach_words * sizeof(uint32_t), st));   // counts and `done` stay zero between launches
     }
     uint32_t *reach = a->d_reach, *counts = reach + qk::kReachMaxTiles, *cursor = counts + qk::kReachMaxTiles + 1;
     uint32_t *done = cursor + qk::kReachMaxTiles + 1;
+    unsigned long long *prefix = reinterpret_cast<unsigned long long *>(reach + 3 * (size_t)qk::kReachMaxTiles + 4);
     const size_t lds = (pl.n_tiles + 2) * sizeof(uint32_t);
     // few blocks: every block costs one same-address atomic per bucket (~15 ns each, serialised)
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 1024, (uint64_t)a->n_cu * 4));
-    hipLaunchKernelGGL(qk::reach_count_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, st, hp, counts, done, reach, cursor);
+    hipLaunchKernelGGL(qk::reach_count_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, st, hp, counts, done, reach, cursor, prefix);
     hipLaunchKernelGGL(qk::reach_scatter_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, st, hp, cursor, a->d_order);
     QK_HIP(hipGetLastError());
     hp.order = a->d_order;
     hp.reach = reach;
+    hp.tile_prefix = prefix;
+  }
+  // several tiles and every tile's work known (reads sorted by reach): equal static shares instead of
+  // the slice queues; an item is then as large as the u16 counters allow.  (Fixed-length long reads know
+  // their work too, but measured SLOWER this way, 0.60 -> 0.66 ms per 143k x 10.5 kb: their workgroups
+  // then march through equally strided addresses in lockstep; the queues desynchronise them.)
+  if (pl.dynamic && pl.sorted && !getenv("QUACK_HIP_NO_STATIC")) {
+    hp.static_split = 1;
+    const uint64_t step = (uint64_t)pl.rw * (uint32_t)pl.unroll;
+    hp.reads_per_slice = (qk::kMaxReadsPerSlice - step) / step * step;
   }
   hp.row_dwords = qk::hist_row_dwords(pl.ch, pl.fused_adapters);
   hp.replicas = qk::hist_replicas(pl.ch, pl.fused_adapters);
