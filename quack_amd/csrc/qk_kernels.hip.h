@@ -399,6 +399,14 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
       if (c) atomicAdd(row0 + 2u * TL, (unsigned long long)c);
       if (g) atomicAdd(row0 + 3u * TL, (unsigned long long)g);
     }
+    if (!FAST_FIXED && !p.lengths_done) {
+      // reads that END in this tile (staged once per tile they reach, so each read counts exactly once)
+      for (uint32_t pp = tid; pp < TP; pp += T) {
+        const uint32_t c = lds_len[pp];
+        if (c != 0 && P0 + pp < p.table_len)
+          atomicAdd(&p.table[(uint64_t)kRowLength * TL + P0 + pp], (unsigned long long)c);
+      }
+    }
     if (tile == 0) {
       if (FAST_FIXED) {
         if (tid == 0 && fixed_reads != 0) {
@@ -409,11 +417,6 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             atomicAdd(&p.table[(uint64_t)kRowKmer * TL + 10u], n);                 // quack.c:215-217, i == 10
         }
       } else {
-        for (uint32_t pp = tid; pp < TP; pp += T) {
-          const uint32_t c = lds_len[pp];
-          if (c != 0 && pp < p.table_len)
-            atomicAdd(&p.table[(uint64_t)kRowLength * TL + pp], (unsigned long long)c);
-        }
         if (tid == 0 && p.no_adapters && lds_misc[0] != 0)
           atomicAdd(&p.table[(uint64_t)kRowKmer * TL + 10u], (unsigned long long)lds_misc[0]);
       }
@@ -501,16 +504,15 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             }
             if ((AL || p.check_aligned) && (o0 & 127u) != 0) atomicOr(p.status, 1u);   // the producer's promise does not hold
           }
-          if (tile == 0 && !p.lengths_done) {   // wave-uniform
-            // length_count and the kmers==NULL count (quack.c:215-219), once per read.
-            // Real batches are dominated by a few lengths (untrimmed reads), and
-            // 64 lanes adding to one address serialise — for lengths past the
-            // tile that is one global address (measured: 143k reads of one
-            // length 1.89 ms instead of 0.68).  So the wave first adds up to four
-            // of its most frequent... rather, first-met lengths as a whole.
-            n_gt10 += (i < nb && len > 10u) ? 1u : 0u;
-            bool todo = i < nb && len != 0;
-            const uint32_t lp = len - 1u;
+          if (!p.lengths_done) {   // wave-uniform
+            // length_count (quack.c:219) of the reads that END in this tile — every read is staged
+            // once for every tile it reaches, so once for its last — and, at tile 0, the kmers==NULL
+            // count (quack.c:215).  Real batches are dominated by a few lengths (untrimmed reads), and
+            // 64 lanes adding to one LDS address serialise (143k reads of one length: 1.89 ms instead of
+            // 0.68), so the wave first adds up its first-met lengths as a whole.
+            if (tile == 0) n_gt10 += (i < nb && len > 10u) ? 1u : 0u;
+            const uint32_t lp = len - 1u - P0;   // position of the last base inside this tile (if it is)
+            bool todo = i < nb && len > P0 && lp < TP;
             uint64_t left = __builtin_amdgcn_ballot_w64(todo);
             for (int k = 0; k < 4 && left; ++k) {
               const uint32_t leader = (uint32_t)__builtin_ctzll(left);
@@ -518,19 +520,11 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
               const uint64_t same = __builtin_amdgcn_ballot_w64(todo && lp == v);
               const uint32_t cnt = (uint32_t)__builtin_popcountll(same);
               if (cnt < 4u) break;   // all different: plain atomics do as well
-              if (lane_id == leader) {
-                if (v < TP) lds_add(lds_len, v * 4u, cnt);
-                else atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + v], (unsigned long long)cnt);
-              }
+              if (lane_id == leader) lds_add(lds_len, v * 4u, cnt);
               if (lp == v) todo = false;
               left &= ~same;
             }
-            if (todo) {
-              if (lp < TP)
-                lds_add(lds_len, lp * 4u, 1u);
-              else
-                atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + lp], 1ull);
-            }
+            if (todo) lds_add(lds_len, lp * 4u, 1u);
           }
           const bool reach = i < nb && len > P0;
           const uint64_t vote = __builtin_amdgcn_ballot_w64(reach);
@@ -1026,40 +1020,27 @@ __device__ __forceinline__ void wave_count_global(unsigned long long *row, uint3
 }
 
 // counts[k] += reads of bucket k (counts: n_tiles + 1 words, zero on entry and
-// on exit), and the batch's length_count / kmers==NULL count while the lengths
-// are in hand; the block that finishes last turns the counts into
+// on exit); the block that finishes last turns the counts into
 //   reach[t]  = reads in buckets > t
 //   cursor[k] = first slot of bucket k in order[] (longest reads first)
 __global__ __launch_bounds__(kReachThreads) void reach_count_kernel(const HistParams p, uint32_t *counts, uint32_t *done,
                                                                     uint32_t *reach, uint32_t *cursor, unsigned long long *prefix) {
   extern __shared__ uint32_t lc[];   // n_tiles + 1 counters, + 1 word for the ticket
-  __shared__ uint32_t len_cnt[kLenLds];   // ... and the batch's length_count on the way (ragged_length_kernel's job)
-  __shared__ uint32_t gt10;
   const uint32_t nb = p.n_tiles + 1u;
   for (uint32_t i = threadIdx.x; i < nb; i += kReachThreads) lc[i] = 0;
-  for (uint32_t i = threadIdx.x; i < kLenLds; i += kReachThreads) len_cnt[i] = 0;
-  if (threadIdx.x == 0) gt10 = 0;
   __syncthreads();
-  uint32_t mine = 0;
-  // (whole waves per round: the wave_count_* helpers use ballots)
+  // (whole waves per round: wave_count_lds uses ballots.  length_count is hist_kernel's business: it
+  // meets every read once in the tile the read ends in)
   for (uint64_t r0 = (uint64_t)blockIdx.x * kReachThreads; r0 < p.n_reads; r0 += (uint64_t)gridDim.x * kReachThreads) {
     const uint64_t r = r0 + threadIdx.x;
     const bool in = r < p.n_reads;
     const uint32_t len = !in ? 0u : (p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]));
     const uint32_t k = (len + p.tile_pos - 1u) / p.tile_pos;
     wave_count_lds(lc, k < p.n_tiles ? k : p.n_tiles, in);
-    mine += len > 10u ? 1u : 0u;
-    wave_count_lds(len_cnt, len - 1u, len != 0 && len - 1u < kLenLds);
-    wave_count_global(&p.table[(uint64_t)kRowLength * p.table_len], len - 1u, len != 0 && len - 1u >= kLenLds);
   }
-  if (mine) atomicAdd(&gt10, mine);
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < nb; i += kReachThreads)
     if (lc[i]) atomicAdd(&counts[i], lc[i]);
-  for (uint32_t i = threadIdx.x; i < kLenLds && i < p.table_len; i += kReachThreads)
-    if (len_cnt[i]) atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + i], (unsigned long long)len_cnt[i]);
-  if (threadIdx.x == 0 && p.no_adapters && gt10)
-    atomicAdd(&p.table[(uint64_t)kRowKmer * p.table_len + 10u], (unsigned long long)gt10);
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) lc[nb] = atomicAdd(done, 1u);

@@ -495,9 +495,9 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   // (with two or three tiles nearly every read reaches every tile: nothing to gain)
   pl.sorted = pl.dynamic && d_off != nullptr && total_bytes < 0xFFFFFF00ull && pl.n_tiles >= 4 &&
               pl.n_tiles <= qk::kReachMaxTiles && !getenv("QUACK_HIP_NO_SORT");
-  if ((pl.dynamic && d_off != nullptr && !pl.sorted) || strided) {
-    // several tiles: lengths past the tile width have no LDS counter inside hist_kernel
-    // (the sorted path takes them in its counting pass)
+  if (strided) {
+    // strided batches have no staging pass that could count the lengths on the way
+    // (ragged batches of several tiles: hist_kernel counts a read's length in the tile it ends in)
     const unsigned lb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 8192, (uint64_t)a->n_cu));
     if (strided && stride <= qk::kShortLen)
       hipLaunchKernelGGL(qk::short_length_kernel, dim3(lb), dim3(qk::kLenThreads), 0, st, hp);
@@ -507,7 +507,6 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     hp.lengths_done = 1;
   }
   if (pl.sorted) {
-    hp.lengths_done = 1;
     if (a->order_cap < n_reads) {
       QK_HIP(hipDeviceSynchronize());
       if (a->d_order) QK_HIP(hipFree(a->d_order));
@@ -539,7 +538,9 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   // the slice queues; an item is then as large as the u16 counters allow.  (Fixed-length long reads know
   // their work too, but measured SLOWER this way, 0.60 -> 0.66 ms per 143k x 10.5 kb: their workgroups
   // then march through equally strided addresses in lockstep; the queues desynchronise them.)
-  if (pl.dynamic && pl.sorted && !getenv("QUACK_HIP_NO_STATIC")) {
+  // (And beyond ~32 kb — more than 64 tiles — the queues win again: 30k x 10-50 kb 0.459 static vs 0.435,
+  // 3000 x 100-500 kb 1.18 vs 0.95; up to there static wins: 300k x 0.1-5 kb 0.355 vs 0.410, config 5.)
+  if (pl.dynamic && pl.sorted && pl.n_tiles <= 64 && !getenv("QUACK_HIP_NO_STATIC")) {
     hp.static_split = 1;
     const uint64_t step = (uint64_t)pl.rw * (uint32_t)pl.unroll;
     hp.reads_per_slice = (qk::kMaxReadsPerSlice - step) / step * step;
