@@ -370,6 +370,14 @@ uint64_t qkh_inflate_bitpos(const qkh_inflate *z) {
 #undef READ_FN
 #undef COPY_FN
 
+void qkh_inflate_clone(qkh_inflate *dst, const qkh_inflate *src) {
+  *dst = *src;
+  if (src->litlen == src->fixed_litlen) dst->litlen = dst->fixed_litlen;
+  else if (src->litlen == src->dyn_litlen) dst->litlen = dst->dyn_litlen;
+  if (src->dist == src->fixed_dist) dst->dist = dst->fixed_dist;
+  else if (src->dist == src->dyn_dist) dst->dist = dst->dyn_dist;
+}
+
 /* ------------------------------------------------------------ member ends */
 int qkh_end_list_take(qkh_end_list *l, const qkh_inflate *z, size_t before) {
   for (unsigned i = 0; i < z->tl_n; i++) {

@@ -69,6 +69,8 @@ uint32_t qkh_crc32(uint32_t crc, const uint8_t *buf, size_t len);
 size_t qkh_index_lines(const uint8_t *data, size_t len, uint32_t **nl, size_t *cap);
 
 void qkh_inflate_init(qkh_inflate *z, const uint8_t *data, size_t len);
+/* a copy that decodes on from where `src` stands (the table pointers are re-aimed at the copy) */
+void qkh_inflate_clone(qkh_inflate *dst, const qkh_inflate *src);
 
 /* Produce up to `cap` bytes at `out`.  The `history` bytes before `out` must be
  * the previously produced output (up to 32768 are ever referenced).  Returns

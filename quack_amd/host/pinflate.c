@@ -42,6 +42,10 @@ enum { WIN = 32768, MAX_THREADS = 32 };
  * this is 32x) and is decoded in order instead; buffers that grew past KEEP_MAX are given back after use */
 #define SPEC_MAX ((size_t)32 << 20)
 #define KEEP_MAX ((size_t)64 << 20)
+/* ... and the in-order decoder, which has to take whatever a slice inflates to (1 MiB of zeros: 1 GiB),
+ * stops at INORDER_MAX bytes and hands its state over: the caller goes on with the one-thread ring
+ * producer, which streams in constant memory like the reference's gzread (qkh_pinflate_handoff) */
+#define INORDER_MAX ((size_t)256 << 20)
 
 typedef struct {
   uint16_t *b16;   /* WIN markers + speculative output */
@@ -76,6 +80,10 @@ struct qkh_pinflate {
   int chain_end;         /* the stream ended (or broke) inside an earlier slice */
   int n_threads;
   pthread_t threads[MAX_THREADS];
+  /* a slice outgrew the in-order decoder's bound: its decoder, frozen in mid-stream, and the window */
+  int handoff;
+  qkh_inflate handoff_z;
+  size_t inorder_max;
   /* statistics (tests, QUACK_VERBOSE) */
   unsigned kept, redone;
 };
@@ -198,7 +206,7 @@ static void *worker_main(void *arg) {
     size_t n = 0, member_out = 0;
     unsigned members = 0;
     uint64_t end_bit = 0;
-    int end = ended, failed = 0, keep = 0;
+    int end = ended, failed = 0, keep = 0, overflow = 0;
     uint8_t new_win[WIN];
     size_t new_win_len = 0;
 
@@ -237,8 +245,12 @@ static void *worker_main(void *arg) {
           if (qkh_end_list_take(&s->el, z, n)) failed = 1;
           if (got > 0) n += (size_t)got;
           if (z->stopped || z->state == QKH_Z_DONE || z->state == QKH_Z_ERROR || got <= 0) break;
+          if (n >= p->inorder_max) {   /* enough for one slot: the rest of the stream goes to the serial producer */
+            overflow = 1;
+            break;
+          }
         }
-        end = failed || !z->stopped;   /* finished, or broken at this byte: nothing follows */
+        end = failed || overflow || !z->stopped;   /* finished, handed over, or broken at this byte: nothing follows */
         end_bit = qkh_inflate_bitpos(z);
         member_out = z->member_out;
         members = z->members;
@@ -260,6 +272,12 @@ static void *worker_main(void *arg) {
       p->chain_members = members;
       p->chain_end = end;
       if (failed) p->failed = 1;
+      if (overflow && !failed) {
+        qkh_inflate_clone(&p->handoff_z, z);
+        p->handoff_z.stop_bit = 0;
+        p->handoff_z.stopped = 0;
+        p->handoff = 1;
+      }
       if (keep) p->kept++;
       else p->redone++;
     }
@@ -302,6 +320,10 @@ qkh_pinflate *qkh_pinflate_open(const uint8_t *data, size_t len, int threads, si
   p->n_slices = (unsigned)((len + slice_bytes - 1) / slice_bytes);
   if (!p->n_slices) p->n_slices = 1;
   p->n_slots = (unsigned)threads + 4;
+  {
+    const char *e = getenv("QUACK_PGZIP_MAX_SLICE_MB");   /* (tests) */
+    p->inorder_max = e && atoi(e) > 0 ? (size_t)atoi(e) << 20 : INORDER_MAX;
+  }
   p->slots = calloc(p->n_slots, sizeof *p->slots);
   pthread_mutex_init(&p->mu, NULL);
   pthread_cond_init(&p->cv, NULL);
@@ -375,6 +397,19 @@ void qkh_pinflate_lines(qkh_pinflate *p, const uint32_t **nl, size_t *n) {
   const pslot *s = &p->slots[p->tail % p->n_slots];
   *nl = s->nl;
   *n = p->holding ? s->n_nl : (size_t)-1;
+}
+
+int qkh_pinflate_handoff(qkh_pinflate *p, qkh_inflate *z, uint8_t *window, size_t *window_len) {
+  int h;
+  pthread_mutex_lock(&p->mu);
+  h = p->handoff && (p->chain_end && p->tail == p->next_slice);   /* ... and everything before it was taken */
+  if (h) {
+    qkh_inflate_clone(z, &p->handoff_z);
+    memcpy(window, p->chain_win, p->chain_win_len);
+    *window_len = p->chain_win_len;
+  }
+  pthread_mutex_unlock(&p->mu);
+  return h;
 }
 
 void qkh_pinflate_stats(const qkh_pinflate *p, unsigned *kept, unsigned *redone) {

@@ -19,6 +19,11 @@ int qkh_pinflate_next(qkh_pinflate *p, const uint8_t **data, size_t *len);
 void qkh_pinflate_ends(qkh_pinflate *p, const qkh_member_end **ends, unsigned *n_ends, const uint32_t **piece_crc);
 /* newline offsets of that slice (n == (size_t)-1: none) */
 void qkh_pinflate_lines(qkh_pinflate *p, const uint32_t **nl, size_t *n);
+/* After qkh_pinflate_next returned 0: 1 if the stream is NOT over but a slice outgrew the in-order
+ * decoder's memory bound (a hostile or extremely compressible file).  *z then decodes on from the
+ * exact point with the window's last *window_len bytes (<= 32768) as history: the caller goes on
+ * with the constant-memory serial producer. */
+int qkh_pinflate_handoff(qkh_pinflate *p, qkh_inflate *z, uint8_t *window, size_t *window_len);
 /* slices whose speculative decode was kept / that were decoded again in order */
 void qkh_pinflate_stats(const qkh_pinflate *p, unsigned *kept, unsigned *redone);
 void qkh_pinflate_close(qkh_pinflate *p);

@@ -246,6 +246,34 @@ static void *serial_main(void *arg) {
   return NULL;
 }
 
+/* the multi-threaded decoder handed its state over (qkh_pinflate_handoff): ring + serial producer from there */
+static int start_serial_after_pgzip(qkh_source *s) {
+  qkh_inflate *z = malloc(sizeof *z);
+  uint8_t *hist = malloc(HIST);
+  size_t hist_len = 0;
+  if (!z || !hist || !qkh_pinflate_handoff(s->pz, z, hist, &hist_len)) {
+    free(z);
+    free(hist);
+    return 0;
+  }
+  qkh_pinflate_close(s->pz);
+  s->pz = NULL;
+  s->zf = z;
+  s->hist = hist;
+  s->hist_len = hist_len;
+  s->n_ring = SERIAL_RING;
+  s->ring = calloc(s->n_ring, sizeof *s->ring);
+  if (!s->ring) return 0;
+  for (unsigned i = 0; i < s->n_ring; i++) {
+    if (!(s->ring[i].base = malloc(HIST + BLOCK_BYTES))) return 0;
+    s->ring[i].data = s->ring[i].base + HIST;
+  }
+  if (pthread_create(&s->threads[0], NULL, serial_main, s)) return 0;
+  s->n_threads = 1;
+  snprintf(s->kind, sizeof s->kind, "pgzip -> inflate_fast");
+  return 1;
+}
+
 /* -------------------------------------------------------------------- bgzf */
 /* total size of the BGZF member at p (0 if p does not start one) */
 static size_t bgzf_member_size(const uint8_t *p, const uint8_t *end) {
@@ -484,8 +512,11 @@ static int raw_next(qkh_source *s, const uint8_t **data, size_t *len, const qkh_
     if (r) {
       qkh_pinflate_ends(s->pz, ends, n_ends, piece_crc);
       qkh_pinflate_lines(s->pz, nl, n_nl);
+      return r;
     }
-    return r;
+    /* the end — or a slice that outgrew the parallel decoder's memory bound: then the one-thread ring
+     * producer takes over from the exact bit, in constant memory like the reference's gzread */
+    if (!start_serial_after_pgzip(s)) return 0;
   }
   for (;;) {
     block *b;

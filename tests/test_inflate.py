@@ -185,7 +185,7 @@ def product_tokenize_text(tmp_path, text):
 
 
 # ------------------------------------------------ ordinary gzip, several threads
-def source_bytes(path):
+def source_bytes(path, final_kind=False):
     """the whole decompressed stream as the tokenizer would see it"""
     H = _capi.host()
     H.qkh_source_open.restype = ctypes.c_void_p
@@ -200,6 +200,8 @@ def source_bytes(path):
     d, n, out = ctypes.c_void_p(), ctypes.c_size_t(), []
     while H.qkh_source_next(s, ctypes.byref(d), ctypes.byref(n)):
         out.append(ctypes.string_at(d.value, n.value))
+    if final_kind:
+        kind = H.qkh_source_kind(s).decode()
     H.qkh_source_close(s)
     return kind, b"".join(out)
 
@@ -336,3 +338,31 @@ def test_crc32_fold_is_zlibs_crc32():
         n = rng.choice([rng.randrange(0, 300), rng.randrange(0, 5000), rng.randrange(0, len(blob) - a)])
         start = rng.choice([0, rng.getrandbits(32)])
         assert H.qkh_crc32(start, blob[a:a + n], n) == zlib.crc32(blob[a:a + n], start)
+
+
+def test_a_slice_that_outgrows_the_parallel_decoder_is_streamed_by_the_serial_one(tmp_path, monkeypatch):
+    """the in-order fallback of the multi-threaded decoder had no output bound (1 MiB of zeros
+    inflates to 1 GiB in one slot).  Past the bound the decoder's state is handed to the one-thread ring
+    producer; the bytes are the same (bound lowered to 1 MiB here, the file has a 24 MiB run in one block)"""
+    monkeypatch.setenv("QUACK_THREADS", "4")
+    monkeypatch.setenv("QUACK_PGZIP_CHUNK_KB", "4")
+    monkeypatch.setenv("QUACK_PGZIP_MAX_SLICE_MB", "1")
+    fq = big("fastq")[:2 << 20]
+    text = fq[:1 << 20] + b"@long\n" + b"A" * (24 << 20) + b"\n+\n" + b"I" * (24 << 20) + b"\n" + fq[1 << 20:]
+    p = tmp_path / "run.fq.gz"
+    p.write_bytes(gz(text[:30 << 20], 9) + gz(text[30 << 20:], 6))   # (two members: the CRC chain crosses the hand-over)
+    kind, par = source_bytes(str(p), final_kind=True)
+    assert kind == "pgzip -> inflate_fast"          # the hand-over happened
+    monkeypatch.setenv("QUACK_NO_PGZIP", "1")
+    kind1, ser = source_bytes(str(p))
+    assert kind1 == "inflate_fast"
+    assert par == ser == text
+    # ... and a damaged trailer behind the hand-over still ends the stream where zlib ends it
+    monkeypatch.delenv("QUACK_NO_PGZIP")
+    blob = bytearray(p.read_bytes())
+    blob[-6] ^= 0x08
+    p.write_bytes(bytes(blob))
+    _, par = source_bytes(str(p))
+    monkeypatch.setenv("QUACK_ZLIB", "1")
+    _, ref = source_bytes(str(p))
+    assert par == ref and len(ref) < len(text)
