@@ -481,7 +481,11 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.reads_per_iter = pl.rw;
   hp.n_slices = (uint32_t)pl.n_slices;
   hp.queue = nullptr;
-  if (pl.dynamic) {
+  // (decided here, used below: reads sorted by reach; up to 64 tiles the read-tiles are split statically)
+  pl.sorted = pl.dynamic && d_off != nullptr && total_bytes < 0xFFFFFF00ull && pl.n_tiles >= 4 &&
+              pl.n_tiles <= qk::kReachMaxTiles && !getenv("QUACK_HIP_NO_SORT");
+  const bool static_split = pl.dynamic && pl.sorted && pl.n_tiles <= 64 && !getenv("QUACK_HIP_NO_STATIC");
+  if (pl.dynamic && !static_split) {
     if (pl.n_tiles > kQueueTiles) return fail(QK_EINVAL, "reads of %u bytes need more position tiles than supported", max_len);
     hp.queue = a->d_queues + (size_t)(a->queue_seq++ % kQueueRing) * kQueueTiles;
     QK_HIP(hipMemsetAsync(hp.queue, 0, pl.n_tiles * sizeof(uint32_t), st));
@@ -492,9 +496,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.order = nullptr;
   hp.reach = nullptr;
   hp.lengths_done = 0;
-  // (with two or three tiles nearly every read reaches every tile: nothing to gain)
-  pl.sorted = pl.dynamic && d_off != nullptr && total_bytes < 0xFFFFFF00ull && pl.n_tiles >= 4 &&
-              pl.n_tiles <= qk::kReachMaxTiles && !getenv("QUACK_HIP_NO_SORT");
+  // (with two or three tiles nearly every read reaches every tile: nothing to gain from sorting)
   if (strided) {
     // strided batches have no staging pass that could count the lengths on the way
     // (ragged batches of several tiles: hist_kernel counts a read's length in the tile it ends in)
@@ -540,7 +542,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   // then march through equally strided addresses in lockstep; the queues desynchronise them.)
   // (And beyond ~32 kb — more than 64 tiles — the queues win again: 30k x 10-50 kb 0.459 static vs 0.435,
   // 3000 x 100-500 kb 1.18 vs 0.95; up to there static wins: 300k x 0.1-5 kb 0.355 vs 0.410, config 5.)
-  if (pl.dynamic && pl.sorted && pl.n_tiles <= 64 && !getenv("QUACK_HIP_NO_STATIC")) {
+  if (static_split) {
     hp.static_split = 1;
     const uint64_t step = (uint64_t)pl.rw * (uint32_t)pl.unroll;
     hp.reads_per_slice = (qk::kMaxReadsPerSlice - step) / step * step;

@@ -24,9 +24,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(files):
+    """gpurun merges the files of several calls into one directory: keep the latest run's"""
+    files = sorted(files, key=os.path.getmtime)
+    return files[-1:]
+
+
 def counters(d, kern):
     out = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in newest(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
                 out[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -40,7 +46,7 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     rows = []
-    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+    for f in newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))):
         for r in csv.DictReader(open(f)):
             name = r["Name"]
             r["Name"] = name if len(name) < 100 else name[:60] + "...<%d chars>" % len(name)
