@@ -681,3 +681,45 @@ def test_host_feed_lays_trimmed_reads_out_at_a_fixed_stride(tmp_path, monkeypatc
         sd = quack_amd.read_fastq(str(fq), bits)
         monkeypatch.delenv("QUACK_NO_STRIDE")
         assert_same((sd.bases, sd.number_of_sequences), want)
+
+
+# ---------------------------------------------------------------- long ragged reads: reach sort + static split
+@pytest.mark.parametrize("n,lo,hi,adapters", [(50, 1000, 20000, False), (300, 5000, 5000, False), (3000, 0, 9000, True),
+                                              (700, 2049, 2049, False), (40000, 1500, 3000, False), (257, 511, 40000, True)])
+def test_long_ragged_reads_static_split(n, lo, hi, adapters):
+    """4..64 tiles: the reads are sorted by reach and the read-tiles are cut into one share per workgroup —
+    fewer reads than workgroups, equal lengths (every tile the same work), zero-length reads in between,
+    a length one past a tile boundary, more reads than one item may hold, packed and on cache lines"""
+    import torch
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads) if adapters else None
+    bits = ob.kmers_to_bitset(k) if adapters else None
+    seq, qual, off = synth.ragged(n, lo, hi, seed=n + hi, q_lo=1, q_hi=60, alphabet=b"ACGTNacgt")
+    seq = seq.copy()
+    if adapters:
+        rng = np.random.default_rng(8)
+        for r in rng.integers(0, n, n // 3):
+            a, e = int(off[r]), int(off[r + 1])
+            if e - a > 100:
+                ad = np.frombuffer(ads[r % len(ads)], np.uint8)
+                at = a + int(rng.integers(0, e - a - 50))
+                seq[at:at + len(ad)] = ad[:max(0, min(len(ad), e - at))]
+    want = ob.accumulate_batch(seq, qual, off, kmers=k)
+    assert_same(hip_table(seq, qual, off, kmers_bits=bits), want)                  # packed, through the pinned slots
+    lens = np.diff(off.astype(np.int64))
+    starts = np.concatenate([[0], np.cumsum((lens + 127) // 128 * 128)])[:-1].astype(np.uint64)
+    extent = int(starts[-1] + lens[-1]) if n else 0
+    s2 = np.full(extent, ord("T"), np.uint8)
+    q2 = np.full(extent, 70, np.uint8)
+    for r in range(n):
+        a, l = int(starts[r]), int(lens[r])
+        s2[a:a + l] = seq[int(off[r]):int(off[r]) + l]
+        q2[a:a + l] = qual[int(off[r]):int(off[r]) + l]
+    with quack_amd.Accumulator(0, bits) as acc:                                    # on cache lines, device-resident, twice
+        d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+        d_st, d_l = torch.from_numpy(starts.astype(np.int64)).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda()
+        for _ in range(2):
+            acc.submit_device_gapped(d_s, d_q, d_st, d_l, n, extent, int(lens.max()), aligned=True)
+        sd = acc.finish()
+    assert sd.number_of_sequences == 2 * want[1]
+    assert_same((sd.bases, want[1]), (2 * want[0], want[1]))
