@@ -563,8 +563,15 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
           de[u] = lds_list[in_list ? rel : 0u];
         }
       };
+      // FIXED: byte offset of the lane's chunk in the reads of step 0 — the step's own part, it * read_len,
+      // is wave-uniform and computed by the scalar unit (one v_add per read instead of a v_mad_u64_u32,
+      // the only 32-bit integer multiply-add there is: quarter rate)
+      uint32_t fixed_off0[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) fixed_off0[u] = FIXED ? ((uint32_t)u * RW + ri) * p.read_len + cposp : 0u;
       auto issue = [&](uint32_t it, u32x3 (&q)[U], u32x3 (&s)[U], uint32_t (&nv)[U], uint32_t (&sk)[U],
                        uint32_t (&rl)[U]) __attribute__((always_inline)) {
+        const uint32_t it_bytes = FIXED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)it) * p.read_len : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t rel = it + (uint32_t)u * RW + ri;   // index into the slice (FIXED) / the staged list
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
           const bool in_list = rel < n_list && ri < RW;
           uint32_t off, len;
           if (FIXED) {
-            off = rel * p.read_len + cposp;
+            off = it_bytes + fixed_off0[u];
             len = p.read_len;
           } else {
             const uint2 e = PD > 1 ? lds_list[in_list ? rel : 0u] : de[u];
