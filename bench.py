@@ -85,6 +85,8 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--device", type=int, default=None, help="force this device for every rank")
     ap.add_argument("--reads", type=int, default=None, help="override reads per GPU (rehearsals)")
+    ap.add_argument("--read-len", type=int, default=None,
+                    help="override the read length of a fixed-length workload (kernel exploration; the line says so)")
     ap.add_argument("--quality", default="uniform", choices=["uniform", "novaseq4"],
                     help="novaseq4: Q in {2,12,23,37} with 3/5/12/80 %% (stress for same-bin LDS atomics)")
     return ap.parse_args()
@@ -371,6 +373,9 @@ def main():
     w = dict(WORKLOADS[name])
     if args.reads:
         w["n"] = args.reads
+    if args.read_len and not w["ragged"]:
+        w["L"] = args.read_len
+        w["label"] += " [read length overridden: %d]" % args.read_len
     bits, ads = synthetic_adapter_bits(np) if w["adapters"] else (None, None)
     b = make_batch(torch, np, w, seed=2 + rank, device=device, quality=args.quality, ads=ads)
     seq, qual, d_off, d_len = b["seq"], b["qual"], b["d_off"], b["d_len"]

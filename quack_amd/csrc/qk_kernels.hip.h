@@ -148,20 +148,26 @@ constexpr uint32_t kKeyT = 0x14141414u, kKeyC = 0x03030303u, kKeyG = 0x07070707u
 
 // LDS image (dwords): quality histogram [128][row_dwords] | base counters
 // [4: valid,T,C,G][8*ch] | length_count [8*ch] | misc[4]
-// Short reads put several reads into one 32-lane group; with one column set
-// their lanes would collide on a bank (L=36: 7-way).  R replicas of the
-// columns, picked by (read index in the iteration) % R, spread them over the
-// banks; the flush sums the replicas.  R = 1 from 11 chunks per read up (two
-// reads per group collide at most 2-way, which the LDS hides).
-// With the adapter tables resident the LDS is tight: the rows then stay within
-// 160 dwords (R <= 40 / CH, one replica fewer for 41-56 and 65-80 bp reads).
-inline __host__ __device__ uint32_t hist_replicas(uint32_t ch, bool adapt = false) {
-  if (ch > 10u) return 1u;
-  const uint32_t r = (32u + ch - 1u) / ch + 1u;
-  return adapt && r > 40u / ch ? 40u / ch : r;
-}
-inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch, bool adapt = false) {
-  return (4u * hist_replicas(ch, adapt) * ch + 31u) / 32u * 32u;
+// Bank balance of the quality counters.  An LDS atomic of a wave costs the CU
+// 2 cycles x (the most lanes that meet in one of the 32 banks) — measured,
+// tools/lds_rate.hip: 4.2 cycles at two lanes per bank, 7.3 at four, 128 when all
+// 64 hit one address — and a wave holds the chunk lanes of several reads, which
+// all want the same columns.  So the columns exist as S = 4 R "sets" of CH
+// dwords, laid side by side (set s at dword s * CH): the lanes of read row ri
+// use set (ri + i) % S in their i-th counting instruction, which makes the 64
+// lanes of a wave touch 64 CONSECUTIVE dwords of the row (two lanes per bank; a
+// third where the window wraps around the end of the sets).  Set s counts byte
+// s % 4 of a quality dword (positions s % 4 and s % 4 + 4 of the chunk in the
+// two u16 halves), so a lane takes its bytes in rotated order — one v_alignbit
+// per dword — and only R replicas of the counters exist, not S; the flush sums
+// the replicas.  R = 40 / CH keeps a row within 160 dwords (80 KiB), which is
+// what fits next to the adapter tables; wider tiles have R = 1.
+// (lanes per bank, worst over the wave, mean over waves and instructions:
+//  150 bp 3.9 -> 2.4, 300 bp 3.4 -> 2.3, 100 bp 5.0 -> 2.4, 36 bp 3.2 -> 2.0;
+//  the ideal is 2.0)
+inline __host__ __device__ uint32_t hist_replicas(uint32_t ch) { return ch >= 40u ? 1u : 40u / (ch ? ch : 1u); }
+inline __host__ __device__ uint32_t hist_row_dwords(uint32_t ch, uint32_t replicas) {
+  return (4u * replicas * ch + 31u) / 32u * 32u;
 }
 constexpr uint32_t kFusedFilterLog2 = 18;   // 2^18-bit 9-mer filter = 32 KiB of LDS
 constexpr uint32_t kFusedFilterWords = (1u << kFusedFilterLog2) / 32u;
@@ -175,9 +181,9 @@ constexpr uint32_t kStageReadsMax = 8192;
 // against the exact table when the queue holds a wave's worth of entries.
 constexpr uint32_t kCandCap = 96;                       // entries per wave: drained above 32, a step adds <= 64
 constexpr uint32_t kCandWords = 16u * kCandCap * 2u;    // 16 waves x 96 entries x 8 bytes = 12 KiB
-inline size_t hist_lds_bytes(uint32_t ch, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false,
+inline size_t hist_lds_bytes(uint32_t ch, uint32_t replicas, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false,
                              uint32_t stage_reads = kStageReads) {
-  return ((size_t)kQRows * hist_row_dwords(ch, adapt) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords + kCandWords : 0u)) * sizeof(uint32_t) +
+  return ((size_t)kQRows * hist_row_dwords(ch, replicas) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords + kCandWords : 0u)) * sizeof(uint32_t) +
          (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)stage_reads * (adapt ? 12 : 8) : 0);
 }
 
@@ -210,6 +216,48 @@ __device__ __forceinline__ uint32_t lds_abs_u8(uint32_t byte_addr) {
   return *(lds_const_u8 *)byte_addr;
 #else
   return byte_addr & 0u;   // host pass of the single-source compile: never called
+#endif
+}
+
+// ---- quality histogram layout and address -----------------------------------
+// The u16-pair counters of a tile are kept as PLANES of 128 rows x 32 dwords:
+// column c (0 .. row_dwords) of quality row b lives at dword
+//     (c / 32) * 4096 + b * 32 + (c % 32)
+// so that bank == column (as with one long row per quality value) AND the byte
+// address is  (b << 7) | lane_constant  with disjoint bit fields.  On gfx950 the
+// VALU has two cost classes (tools/instr_rate.hip): v_lshrrev by a constant,
+// v_and/v_or and v_bitop3 on VGPRs issue at full rate, while v_bfe, v_mad_u32_u24,
+// every left shift and every VOP3 with an SGPR/literal operand take ~1.7x as
+// long.  The address of byte J of a quality dword is therefore
+//     J >= 1:  v_lshrrev(8J-7) ; v_bitop3 (x & 0x3F80) | qcol      (2 fast ops)
+//     J == 0:  v_and 0x7F ; v_lshl_or 7                            (1 fast, 1 slow)
+// instead of v_bfe + v_mad_u32_u24 (2 slow ops) per base.
+constexpr uint32_t kPlaneDwords = 128u * 32u;
+__host__ __device__ constexpr uint32_t qhist_index(uint32_t row, uint32_t col) {
+  return (col >> 5) * kPlaneDwords + row * 32u + (col & 31u);
+}
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+template <int J, uint32_t BASE>
+__device__ __forceinline__ void qhist_add(uint32_t w, uint32_t mask7, uint32_t qcol, uint32_t val) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t addr;
+#ifdef QK_QADDR_SLOW   // A/B: the two-slow-op address (v_bfe + v_mad_u32_u24) on the same layout
+  addr = __umul24(__builtin_amdgcn_ubfe(w, 8 * J, 7), 128u) + qcol;
+  (void)mask7;
+#else
+  if (J == 0) {
+    const uint32_t t = w & 0x7Fu;
+    asm("v_lshl_or_b32 %0, %1, 7, %2" : "=v"(addr) : "v"(t), "v"(qcol));
+  } else {
+    const uint32_t s = w >> (8 * J - 7);
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(addr) : "v"(s), "v"(mask7), "v"(qcol));
+  }
+#endif
+  // absolute LDS address: BASE (bytes, a compile-time constant) goes into the
+  // instruction's offset field
+  __hip_atomic_fetch_add((lds_u32 *)addr + BASE / 4u, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  (void)w; (void)mask7; (void)qcol; (void)val;
 #endif
 }
 
@@ -301,11 +349,18 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   const int32_t ch_signed = (int32_t)chh - (int32_t)H;
   const uint32_t RW = p.reads_per_iter;
   const bool lane_on = lane_id >= feeders && !is_halo && ri < RW;
-  const uint32_t row_bytes = 4u * RD;   // a multiple of 128 B: bank == column
+  // byte address, in quality row 0, of the counter column this lane's i-th counting
+  // instruction adds to (see hist_replicas): set (ri + i) % S, which holds byte
+  // (ri + i) % 4 of the quality dword — byte i after a rotation by rot8 bits
   uint32_t qcol[4];
   const uint32_t R = p.replicas;
+  const uint32_t kset = ri % (4u * R);
+  const uint32_t rot8 = 8u * (kset & 3u);
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) qcol[jj] = ((jj * R + ri % R) * CH + ch) * 4u;
+  for (int i = 0; i < 4; ++i) qcol[i] = qhist_index(0u, ((kset + i) % (4u * R)) * CH + ch) * 4u;
+  constexpr uint32_t kHistBase = ADAPT ? (kFusedFilterWords + kCandWords) * 4u : 0u;   // == (char*)lds - LDS byte 0
+  uint32_t mask7;   // 127 << 7 in a VGPR (an SGPR or literal operand would put v_bitop3 in the slow class)
+  asm("v_mov_b32 %0, 0x3f80" : "=v"(mask7));
   const uint32_t one_lo = 1u, one_hi = 65536u;
 
   // ADAPT: this wave's candidate queue (see kCandCap) and its fill (wave-uniform)
@@ -379,7 +434,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
         const uint32_t c8 = pp >> 3, j = pp & 7u;
         uint32_t c = 0;
         for (uint32_t rep = 0; rep < R; ++rep) {
-          const uint32_t w = lds[row * RD + ((j & 3u) * R + rep) * CH + c8];
+          const uint32_t w = lds[qhist_index(row, (rep * 4u + (j & 3u)) * CH + c8)];
           c += (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
         }
         const uint32_t pos = P0 + pp;
@@ -733,9 +788,12 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
           qwU[u][1] = qw[1];
         } else if ((MODE == 0 || MODE == 2) && count_me) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const uint32_t b = __builtin_amdgcn_ubfe(qw[j >> 2], 8 * (j & 3), 7);
-            lds_add(lds, __umul24(b, row_bytes) + qcol[j & 3], (j >> 2) ? one_hi : one_lo);
+          for (int jj = 0; jj < 2; ++jj) {
+            const uint32_t wr = __builtin_amdgcn_alignbit(qw[jj], qw[jj], rot8);
+            qhist_add<0, kHistBase>(wr, mask7, qcol[0], jj ? one_hi : one_lo);
+            qhist_add<1, kHistBase>(wr, mask7, qcol[1], jj ? one_hi : one_lo);
+            qhist_add<2, kHistBase>(wr, mask7, qcol[2], jj ? one_hi : one_lo);
+            qhist_add<3, kHistBase>(wr, mask7, qcol[3], jj ? one_hi : one_lo);
           }
         }
         if (MODE == 0 || MODE == 3) {
@@ -793,10 +851,25 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
           if (!liveU[u]) continue;   // (wave-uniform)
           const uint32_t n = nU[u];
           if (!FAST_FIXED || n != 0) {
+#ifdef QK_DUMMY_VALU   // sensitivity probe (tools only): N extra VALU instructions per chunk
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const uint32_t b = __builtin_amdgcn_ubfe(qwU[u][j >> 2], 8 * (j & 3), 7);
-              lds_add(lds, __umul24(b, row_bytes) + qcol[j & 3], (j >> 2) ? one_hi : one_lo);
+            for (int q = 0; q < QK_DUMMY_VALU; ++q) {
+#if QK_DUMMY_SLOW == 2   // an LDS atomic on quality row 0 (never flushed), same bank pattern as the real ones
+              asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(qcol[q & 3]), "v"(one_lo), "i"(kHistBase) : "memory");
+#elif QK_DUMMY_SLOW
+              asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(keep));
+#else
+              asm volatile("v_xor_b32 %0, %0, %1" : "+v"(keep) : "v"(mask7));
+#endif
+            }
+#endif
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const uint32_t wr = __builtin_amdgcn_alignbit(qwU[u][jj], qwU[u][jj], rot8);
+              qhist_add<0, kHistBase>(wr, mask7, qcol[0], jj ? one_hi : one_lo);
+              qhist_add<1, kHistBase>(wr, mask7, qcol[1], jj ? one_hi : one_lo);
+              qhist_add<2, kHistBase>(wr, mask7, qcol[2], jj ? one_hi : one_lo);
+              qhist_add<3, kHistBase>(wr, mask7, qcol[3], jj ? one_hi : one_lo);
             }
           }
         }
@@ -974,6 +1047,9 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   if (MODE == 1) {
     if (keep == 0x12345678u) lds[0] = keep;
   }
+#ifdef QK_DUMMY_VALU
+  if (keep == 0x12345679u) lds[1] = keep;
+#endif
   if (cur_tile != 0xFFFFFFFFu) flush(cur_tile);
 }
 

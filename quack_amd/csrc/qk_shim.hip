@@ -178,7 +178,7 @@ struct Plan {
   int unroll, pipe;
   uint32_t stage_reads;
   uint64_t reads_per_slice, n_slices, n_blocks;
-  uint32_t bucket_log2, halo;
+  uint32_t bucket_log2, halo, replicas;
   bool fused_adapters, dynamic, aligned, sorted;
 };
 constexpr unsigned kQueueRing = 8;       // queue sets that rotate (launches of one accumulator run in order)
@@ -206,7 +206,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   pl->unroll = a->unroll > 0 ? a->unroll : ((want_pipe && !ragged) ? (pl->fused_adapters ? 2 : 1) : 4);
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
   uint32_t single_cap = 576u;
-  while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, a->adapters, 0, ragged) > 160 * 1024)
+  while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, qk::hist_replicas(single_cap / 8), a->adapters, 0, ragged) > 160 * 1024)
     single_cap -= 32u;
   uint32_t cap = a->tile > 0 ? std::max<uint32_t>(8, (uint32_t)a->tile / 8 * 8) : single_cap;
   cap = std::min(cap, single_cap);
@@ -244,16 +244,23 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   if (!ragged && (max_len & 3u) == 0 && base_aligned4 && T == 1024 && !a->unroll && !a->pipe &&
       !getenv("QUACK_HIP_NO_ALIGN4"))
     pl->aligned = true;
+  if (pl->aligned && !ragged && pl->fused_adapters) pl->pipe = env_int("QUACK_HIP_ADAPT_PD", pl->pipe), pl->unroll = env_int("QUACK_HIP_ADAPT_U", pl->unroll);
   pl->n_tiles = n_tiles;
   pl->tile_pos = tile_pos;
   pl->ch = tile_pos / 8;
   pl->halo = (pl->fused_adapters && n_tiles > 1) ? 2u : 0u;   // lanes covering the 16 positions before a tile
   pl->rw = (pl->fused_adapters ? T / 64 * 62 : T) / (pl->ch + pl->halo);
+  // replicas of the quality counters (bank balance, see qk::hist_replicas)
+  pl->replicas = qk::hist_replicas(pl->ch);
+  if (const int r = env_int("QUACK_HIP_REPLICAS", 0)) pl->replicas = std::min<uint32_t>((uint32_t)r, pl->replicas);
   const uint64_t step = (uint64_t)pl->rw * (uint32_t)pl->unroll;
   // the exact table next to the histogram, if it fits (it never narrows a tile: without it
   // the queued candidates are checked against the global table)
   pl->bucket_log2 = pl->fused_adapters ? a->bucket_log2 : 0;
-  if (pl->bucket_log2 && qk::hist_lds_bytes(pl->ch, true, pl->bucket_log2, ragged) > 160 * 1024) pl->bucket_log2 = 0;
+  // (the exact table matters more than the last replica)
+  while (pl->bucket_log2 && pl->replicas > 1 && qk::hist_lds_bytes(pl->ch, pl->replicas, true, pl->bucket_log2, ragged) > 160 * 1024)
+    --pl->replicas;
+  if (pl->bucket_log2 && qk::hist_lds_bytes(pl->ch, pl->replicas, true, pl->bucket_log2, ragged) > 160 * 1024) pl->bucket_log2 = 0;
   // ragged: reads staged per pass.  A pass should hold many steps (36 bp reads: 816 per
   // step, so passes of 1024 staged every 1.25 steps: 1.10 ms per 40M reads, 0.5x the fixed
   // path), as far as the LDS next to the histogram allows
@@ -261,10 +268,10 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   if (ragged) {
     const uint64_t want = step * 12;
     while (pl->stage_reads < qk::kStageReadsMax && pl->stage_reads < want &&
-           qk::hist_lds_bytes(pl->ch, pl->fused_adapters, pl->bucket_log2, true, pl->stage_reads * 2) <= 160 * 1024)
+           qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, true, pl->stage_reads * 2) <= 160 * 1024)
       pl->stage_reads *= 2;
   }
-  const size_t lds = qk::hist_lds_bytes(pl->ch, pl->fused_adapters, pl->bucket_log2, ragged, pl->stage_reads);
+  size_t lds = qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, ragged, pl->stage_reads);
   if (lds > 160 * 1024) return fail(QK_EINVAL, "LDS tile too large (%zu bytes)", lds);
   // residency: the kernels need 89-104 VGPRs, i.e. 4 waves per SIMD = 1024
   // threads per CU, and the LDS image must fit as many times
@@ -272,7 +279,16 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
                                    : std::max<uint32_t>(1, std::min<uint32_t>(1024 / T, (uint32_t)(160 * 1024 / lds)));
   // strided batches without the adapter scan: the kernel is built for 64 VGPRs and runs two
   // workgroups per CU when the LDS holds two histograms (reads of up to ~190 bases)
-  if (strided && !pl->fused_adapters && a->wgs_per_cu <= 0 && T == 1024 && 2 * lds <= 160 * 1024) wgs = 2;
+  if (strided && !pl->fused_adapters && a->wgs_per_cu <= 0 && T == 1024) {
+    if (2 * lds > 160 * 1024 && !getenv("QUACK_HIP_SV_ONE_WG")) {   // fewer replicas, if that admits the second workgroup
+      const size_t lds1 = qk::hist_lds_bytes(pl->ch, 1, false, 0, ragged, pl->stage_reads);
+      if (2 * lds1 <= 160 * 1024) {
+        pl->replicas = 1;
+        lds = lds1;
+      }
+    }
+    if (2 * lds <= 160 * 1024) wgs = 2;
+  }
   // Work items = tiles x read slices.  Single tile: one item per resident
   // workgroup.  Several tiles (long reads): reads do not reach the far tiles
   // equally, so the slices are cut ~16x finer than the resident workgroups and
@@ -338,7 +354,12 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
   if (!strided && aligned && fixed && mode == 0) {
     if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 2))
       k = adapt ? qk::hist_kernel<T, U, true, 0, true, PD, true> : qk::hist_kernel<T, U, true, 0, false, PD, true>;
+    if constexpr (T == 1024 && PD > 2)
+      if (adapt) k = qk::hist_kernel<T, U, true, 0, true, PD, true>;
   }
+  if constexpr (PD > 2) {
+    if (!k) return fail(QK_EINVAL, "pipeline depth %d is built for dword-aligned fixed-length batches with adapters only", PD);
+  } else
   if (k) {
   } else if (adapt) {
     if (mode == 0) k = fixed ? qk::hist_kernel<T, U, true, 0, true, PD> : qk::hist_kernel<T, U, false, 0, true, PD>;
@@ -355,13 +376,14 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
     if (mode == 0) k = qk::hist_kernel<T, U, false, 0, false, PD>;
   }
   if (!k) return fail(QK_EINVAL, "kernel variant not built (mode %d)", mode);
-  if (adapt) {
-    // the fused scan addresses its filter at LDS byte 0 (qk::lds_abs_u8)
+  {
+    // the kernels use absolute LDS addresses (qk::qhist_add; the fused scan's filter at
+    // LDS byte 0, qk::lds_abs_u8): the dynamic segment must start at byte 0
     static bool checked = false;   // per instantiation
     if (!checked) {
       hipFuncAttributes fa;
       QK_HIP(hipFuncGetAttributes(&fa, (const void *)k));
-      if (fa.sharedSizeBytes != 0) return fail(QK_ESTATE, "adapter kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
+      if (fa.sharedSizeBytes != 0) return fail(QK_ESTATE, "histogram kernel has %zu bytes of static LDS", (size_t)fa.sharedSizeBytes);
       checked = true;
     }
   }
@@ -389,12 +411,13 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
 
 int launch_hist(qk_accum *a, const qk::HistParams &hp, const Plan &pl, bool fixed, int mode, bool adapt,
                 hipStream_t st, bool strided = false) {
-  const size_t lds = qk::hist_lds_bytes(hp.ch, adapt, hp.bucket_log2, !fixed, pl.stage_reads);
+  const size_t lds = qk::hist_lds_bytes(hp.ch, pl.replicas, adapt, hp.bucket_log2, !fixed, pl.stage_reads);
   dim3 grid((unsigned)pl.n_blocks);
 #define QK_TU(TT, UU, PP) \
   if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, strided, grid, lds, st);
   QK_TU(1024, 4, 1) QK_TU(1024, 2, 1) QK_TU(1024, 1, 1)
   QK_TU(1024, 4, 2) QK_TU(1024, 2, 2) QK_TU(1024, 1, 2)
+  QK_TU(1024, 2, 3) QK_TU(1024, 2, 4) QK_TU(1024, 1, 4)
   QK_TU(512, 4, 1) QK_TU(512, 2, 1) QK_TU(512, 1, 1)
   QK_TU(256, 4, 1) QK_TU(256, 2, 1)
 #undef QK_TU
@@ -547,8 +570,8 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     const uint64_t step = (uint64_t)pl.rw * (uint32_t)pl.unroll;
     hp.reads_per_slice = (qk::kMaxReadsPerSlice - step) / step * step;
   }
-  hp.row_dwords = qk::hist_row_dwords(pl.ch, pl.fused_adapters);
-  hp.replicas = qk::hist_replicas(pl.ch, pl.fused_adapters);
+  hp.row_dwords = qk::hist_row_dwords(pl.ch, pl.replicas);
+  hp.replicas = pl.replicas;
   hp.halo = pl.halo;
 
   if (a->timing) QK_HIP(hipEventRecord(tl.t0, st));
@@ -754,9 +777,9 @@ int qk_debug_plan(uint64_t n_reads, uint32_t max_len, int ragged, int adapters, 
   if (rc) return rc;
   out[0] = pl.n_tiles; out[1] = pl.tile_pos; out[2] = pl.ch; out[3] = pl.rw;
   out[4] = (uint64_t)pl.unroll; out[5] = (uint64_t)pl.pipe; out[6] = pl.reads_per_slice; out[7] = pl.n_slices;
-  out[8] = pl.n_blocks; out[9] = qk::hist_lds_bytes(pl.ch, pl.fused_adapters, pl.bucket_log2, ragged != 0, pl.stage_reads);
+  out[8] = pl.n_blocks; out[9] = qk::hist_lds_bytes(pl.ch, pl.replicas, pl.fused_adapters, pl.bucket_log2, ragged != 0, pl.stage_reads);
   out[10] = pl.halo; out[11] = pl.fused_adapters; out[12] = pl.dynamic; out[13] = pl.aligned;
-  out[14] = qk::hist_replicas(pl.ch, pl.fused_adapters); out[15] = qk::hist_row_dwords(pl.ch, pl.fused_adapters);
+  out[14] = pl.replicas; out[15] = qk::hist_row_dwords(pl.ch, pl.replicas);
   return QK_OK;
 }
 

@@ -87,6 +87,18 @@ def test_adapters_every_chunk_count_of_short_reads():
         assert_same(hip_table(seq, qual, off, kmers_bits=bits), ob.accumulate_batch(seq, qual, off, kmers=k))
 
 
+@pytest.mark.parametrize("replicas", [None, "1", "3"])
+def test_every_tile_width_and_counter_replica_count(monkeypatch, replicas):
+    """1..64 chunks per read: every layout of the quality counters (sets of columns, byte rotation per read
+    row, replicas summed by the flush — qk::hist_replicas), with the planner's replica count and with fewer"""
+    if replicas:
+        monkeypatch.setenv("QUACK_HIP_REPLICAS", replicas)
+    for L in [3, 8, 15, 16, 17, 24, 33, 47, 56, 64, 79, 90, 101, 125, 149, 176, 211, 250, 255, 256, 301, 390, 448, 509]:
+        n = 2500 if L < 200 else 900
+        seq, qual = synth.fixed(n, L, seed=L, q_lo=1, q_hi=90)
+        assert_same(hip_table(seq, qual, read_len=L), ob.accumulate_batch(seq, qual, read_len=L))
+
+
 def test_many_reads_just_longer_than_a_tile():
     """two or three tiles and few distinct lengths: length_count must not funnel
     through a handful of global addresses (it took 11 ms per 3 Gbases), and the
