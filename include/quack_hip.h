@@ -93,6 +93,10 @@ void qk_accum_destroy(qk_accum *acc);
 int qk_accum_acquire(qk_accum *acc, uint8_t **seq, uint8_t **qual,
                      uint64_t **offsets, uint64_t *cap_bytes,
                      uint64_t *cap_reads);
+/* Slot size: 32 MiB per array by default (QUACK_HIP_BATCH_MB); a batch holds whole reads, so a
+ * read longer than a slot needs bigger ones: drops both slots (waiting for their work) and makes
+ * the next acquire allocate at least min_bytes.  No slot may be held.  Never shrinks. */
+int qk_accum_resize_slots(qk_accum *acc, uint64_t min_bytes);
 /* offsets_used == 0: fixed-length batch of n_reads x read_len. */
 int qk_accum_commit(qk_accum *acc, uint64_t n_reads, uint64_t total_bytes,
                     int offsets_used, uint32_t read_len);

@@ -57,6 +57,7 @@ def hip():
     L.qk_accum_destroy.restype = None
     L.qk_accum_acquire.argtypes = [c_vp, ctypes.POINTER(c_u8p), ctypes.POINTER(c_u8p),
                                    ctypes.POINTER(c_u64p), c_u64p, c_u64p]
+    L.qk_accum_resize_slots.argtypes = [c_vp, ctypes.c_uint64]
     L.qk_accum_commit.argtypes = [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32]
     L.qk_accum_submit.argtypes = [c_vp, c_vp, c_vp, c_vp, ctypes.c_uint64]
     L.qk_accum_submit_fixed.argtypes = [c_vp, c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint64]

@@ -130,8 +130,9 @@ int ensure_slot(qk_accum *a, int i) {
   Slot &s = a->slot[i];
   if (s.h_seq) return QK_OK;
   if (!a->cap_bytes) {
-    const uint64_t mb = (uint64_t)env_int("QUACK_HIP_BATCH_MB", 64);
+    const uint64_t mb = (uint64_t)env_int("QUACK_HIP_BATCH_MB", 32);
     a->cap_bytes = mb << 20;
+    if (const int kb = env_int("QUACK_HIP_BATCH_KB", 0)) a->cap_bytes = (uint64_t)kb << 10;   // (tests: tiny slots)
     a->cap_reads = a->cap_bytes / 32 + 1024;  // >= one read per 32 bytes
   }
   QK_HIP(hipHostMalloc((void **)&s.h_seq, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
@@ -918,6 +919,40 @@ int qk_accum_acquire(qk_accum *a, uint8_t **seq, uint8_t **qual, uint64_t **offs
   return QK_OK;
 }
 
+int qk_accum_resize_slots(qk_accum *a, uint64_t min_bytes) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  if (a->held_slot >= 0) return fail(QK_ESTATE, "a batch is acquired");
+  if (min_bytes > (1ull << 40)) return fail(QK_EINVAL, "slot size out of range");
+  if (a->cap_bytes && min_bytes <= a->cap_bytes) return QK_OK;
+  int rc = set_device(a);
+  if (rc) return rc;
+  // rare (a read longer than every one before it by far): wait for both slots, drop them,
+  // and let the next acquire allocate at the new size
+  for (int i = 0; i < 2; ++i) {
+    Slot &s = a->slot[i];
+    if (s.busy) {
+      QK_HIP(hipEventSynchronize(s.done));
+      s.busy = false;
+    }
+    if (s.stream) QK_HIP(hipStreamSynchronize(s.stream));
+    if (s.h_seq) (void)hipHostFree(s.h_seq);
+    if (s.h_qual) (void)hipHostFree(s.h_qual);
+    if (s.h_off) (void)hipHostFree(s.h_off);
+    if (s.h_len) (void)hipHostFree(s.h_len);
+    if (s.d_len) (void)hipFree(s.d_len);
+    if (s.d_seq) (void)hipFree(s.d_seq);
+    if (s.d_qual) (void)hipFree(s.d_qual);
+    if (s.d_off) (void)hipFree(s.d_off);
+    if (s.d_hit) (void)hipFree(s.d_hit);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.done) (void)hipEventDestroy(s.done);
+    s = Slot{};
+  }
+  a->cap_bytes = round_up(min_bytes, 1u << 20);
+  a->cap_reads = a->cap_bytes / 32 + 1024;
+  return QK_OK;
+}
+
 int qk_accum_commit(qk_accum *a, uint64_t n_reads, uint64_t total, int offsets_used,
                     uint32_t read_len) {
   if (!a) return fail(QK_EINVAL, "acc is NULL");
@@ -977,9 +1012,10 @@ int qk_accum_submit(qk_accum *a, const uint8_t *seq, const uint8_t *qual,
     uint64_t j = i;
     while (j < n_reads && j - i < capr && offsets[j + 1] - base <= capb) ++j;
     if (j == i) {
+      // one read longer than a slot: bigger slots (a batch holds whole reads)
       a->held_slot = -1;
-      return fail(QK_EINVAL, "read %llu (%llu bytes) exceeds the batch slot; raise QUACK_HIP_BATCH_MB",
-                  (unsigned long long)i, (unsigned long long)(offsets[i + 1] - base));
+      if ((rc = qk_accum_resize_slots(a, offsets[i + 1] - base))) return rc;
+      continue;
     }
     const uint64_t bytes = offsets[j] - base;
     memcpy(hs, seq + base, bytes);
@@ -1010,7 +1046,8 @@ int qk_accum_submit_fixed(qk_accum *a, const uint8_t *seq, const uint8_t *qual,
     uint64_t n = std::min<uint64_t>(n_reads - i, capb / read_len);
     if (n == 0) {
       a->held_slot = -1;
-      return fail(QK_EINVAL, "read_len exceeds the batch slot");
+      if ((rc = qk_accum_resize_slots(a, read_len))) return rc;
+      continue;
     }
     memcpy(hs, seq + i * read_len, n * read_len);
     memcpy(hq, qual + i * read_len, n * read_len);

@@ -12,6 +12,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "quack_host.h"
 
@@ -74,7 +75,15 @@ static int is_opt(const char *arg, const char *s, const char *l) {
   return strcmp(arg, s) == 0 || strcmp(arg, l) == 0;
 }
 
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int qkh_main(int argc, char **argv) {
+  const double t_main = now_s();
+  double t_jobs = 0;
   options o = {0};
   uint32_t *bitset = NULL;
   qk_base_info *tab[2] = {NULL, NULL};
@@ -154,12 +163,15 @@ int qkh_main(int argc, char **argv) {
       }
     }
   }
+  t_jobs = now_s();
   if (qkh_render_document(stdout, stderr, o.name, o.adapters != NULL, tab[0], max_len[0], n_reads[0],
                           paired ? tab[1] : NULL, max_len[1], n_reads[1])) {
     fprintf(stderr, "quack: nothing to draw\n");
     goto done;
   }
   rc = 0;                                             /* quack.c:927 */
+  if (getenv("QUACK_VERBOSE"))
+    fprintf(stderr, "[quack] main: accumulate %.3f s, transform+draw %.3f s\n", t_jobs - t_main, now_s() - t_jobs);
 done:
   free(tab[0]);
   free(tab[1]);

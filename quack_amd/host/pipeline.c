@@ -11,6 +11,9 @@
  * the file.
  */
 #include <stdarg.h>
+#include <stdatomic.h>
+#include <sys/mman.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -28,6 +31,9 @@ static int host_fail(const char *fmt, ...) {
   va_end(ap);
   return -1;
 }
+
+static int g_process_exits;
+void qkh_process_exits_after_this(int on) { g_process_exits = on; }
 
 static double now_s(void) {
   struct timespec ts;
@@ -55,18 +61,142 @@ int qkh_device_list(int *devs, int cap) {
   return n;
 }
 
+/* ---- start-up overlap -------------------------------------------------------
+ * Creating an accumulator (HIP runtime start-up, module load, device buffers: 0.2-0.3 s) and
+ * the first use of its pinned slots (0.03 s each) happen on a thread of their own, while the
+ * tokenizer already parses the first reads into ordinary heap batches ("early" batches, 16 MiB
+ * per array, at most 1 GiB in all); those go through the copying feed (qk_accum_submit*) once
+ * the accumulators exist.  Everything after them uses the pinned slots directly. */
+enum { EARLY_BYTES = 16 << 20, EARLY_READS = 1 << 20, EARLY_MAX = 32 };
+typedef struct {
+  uint8_t *seq, *qual;
+  uint64_t *off;
+  int64_t n;
+  uint64_t total;
+  uint32_t uniform;
+} early_batch;
+
+typedef struct {
+  qk_accum **accs;
+  const int *devices;
+  int n_devices, made, failed;
+  const uint32_t *bitset;
+  char err[300];
+  atomic_int done;
+} acc_creator;
+
+static void *acc_creator_main(void *p) {
+  acc_creator *c = p;
+  for (; c->made < c->n_devices; c->made++) {
+    uint8_t *seq, *qual;
+    uint64_t *offsets;
+    qk_accum *a;
+    if (qk_accum_create(&c->accs[c->made], c->devices[c->made], c->bitset, 0)) {
+      snprintf(c->err, sizeof c->err, "device %d: %s", c->devices[c->made], qk_last_error());
+      c->failed = 1;
+      break;
+    }
+    a = c->accs[c->made];
+    /* touch both pinned slots (allocated on first use): two empty batches */
+    for (int k = 0; k < 2 && !c->failed; k++)
+      if (qk_accum_acquire(a, &seq, &qual, &offsets, NULL, NULL) || qk_accum_commit(a, 0, 0, 0, 0)) {
+        snprintf(c->err, sizeof c->err, "device %d: %s", c->devices[c->made], qk_last_error());
+        c->failed = 1;
+      }
+    if (c->failed) {
+      c->made++;   /* created: the caller destroys it */
+      break;
+    }
+  }
+  atomic_store(&c->done, 1);
+  return NULL;
+}
+
+/* memcpy on several threads (an early batch into a pinned slot: 40 MB, ~10 GB/s on one core) */
+typedef struct {
+  void *dst;
+  const void *src;
+  size_t n;
+} copy_job;
+static void *copy_main(void *p) {
+  const copy_job *j = p;
+  memcpy(j->dst, j->src, j->n);
+  return NULL;
+}
+enum { COPY_THREADS = 8 };
+static void parallel_copy(copy_job *jobs, int n_jobs) {
+  /* cut the jobs into pieces of equal size, one thread per piece (this thread takes the last) */
+  copy_job piece[COPY_THREADS];
+  pthread_t th[COPY_THREADS];
+  size_t all = 0, share;
+  int n_piece = 0, started = 0;
+  for (int i = 0; i < n_jobs; i++) all += jobs[i].n;
+  share = all / COPY_THREADS + 4096;
+  for (int i = 0; i < n_jobs; i++) {
+    size_t at = 0;
+    while (at < jobs[i].n) {
+      size_t len = jobs[i].n - at < share ? jobs[i].n - at : share;
+      if (n_piece == COPY_THREADS) {   /* (rounding: the rest goes with the last piece's thread) */
+        memcpy((char *)jobs[i].dst + at, (const char *)jobs[i].src + at, jobs[i].n - at);
+        break;
+      }
+      piece[n_piece].dst = (char *)jobs[i].dst + at;
+      piece[n_piece].src = (const char *)jobs[i].src + at;
+      piece[n_piece].n = len;
+      n_piece++;
+      at += len;
+    }
+  }
+  for (int i = 0; i + 1 < n_piece; i++) {
+    if (pthread_create(&th[i], NULL, copy_main, &piece[i])) break;
+    started++;
+  }
+  for (int i = started; i < n_piece; i++) copy_main(&piece[i]);
+  for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+}
+
+/* heap for an early batch: 2 MiB aligned and marked for transparent huge pages where the kernel
+ * offers them (first-touch faults and the later munmap are per page: 40 MB = 10,000 small ones) */
+static void *early_alloc(size_t n) {
+  void *p = NULL;
+  n = (n + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+  if (posix_memalign(&p, 2u << 20, n)) return NULL;
+#ifdef MADV_HUGEPAGE
+  (void)madvise(p, n, MADV_HUGEPAGE);
+#endif
+  return p;
+}
+
+static void early_free(early_batch *e) {
+  free(e->seq);
+  free(e->qual);
+  free(e->off);
+  memset(e, 0, sizeof *e);
+}
+static void *early_reaper_main(void *p) {
+  early_batch *early = p;
+  for (int i = 0; i < EARLY_MAX; i++) early_free(&early[i]);
+  return NULL;
+}
+
 int qkh_accumulate_file(const char *path, const uint32_t *bitset,
                         const int *devices, int n_devices,
                         qk_base_info **bases_out, uint64_t *max_len,
                         uint64_t *n_reads) {
   qk_accum *accs[64];
   qkh_reader *rd = NULL;
-  int rc = -1, turn = 0, made = 0, long_reads = 0;
+  int rc = -1, turn = 0, made = 0, long_reads = 0, n_early = 0, n_early_made;
+  early_batch early[EARLY_MAX];
+  double t_dbg[4] = {0, 0, 0, 0};
+  pthread_t reaper;
+  int reaping = 0;
+  memset(early, 0, sizeof early);
+  n_early_made = 0;
   uint32_t stride = 0;   /* != 0: short reads of nearly one length, laid out at a fixed stride */
   const int no_stride = getenv("QUACK_NO_STRIDE") != NULL;
   const int verbose = getenv("QUACK_VERBOSE") != NULL;
   const double t0 = now_s();
-  double t_created, t_first = 0, t_parsed;
+  double t_created, t_early, t_first = 0, t_parsed;
   *bases_out = NULL;
   *max_len = *n_reads = 0;
   if (n_devices < 1 || n_devices > 64) return host_fail("bad device count %d", n_devices);
@@ -77,12 +207,86 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
     host_fail("cannot open %s", path);
     goto out;
   }
-  for (; made < n_devices; made++)
-    if (qk_accum_create(&accs[made], devices[made], bitset, 0)) {
-      host_fail("device %d: %s", devices[made], qk_last_error());
+  {
+    acc_creator cr;
+    pthread_t th;
+    int threaded;
+    memset(&cr, 0, sizeof cr);
+    cr.accs = accs;
+    cr.devices = devices;
+    cr.n_devices = n_devices;
+    cr.bitset = bitset;
+    atomic_init(&cr.done, 0);
+    /* (tests shrink the early batches to meet the "read longer than an early batch" case) */
+    const size_t early_bytes = getenv("QUACK_EARLY_BYTES") ? (size_t)strtoull(getenv("QUACK_EARLY_BYTES"), NULL, 10) : (size_t)EARLY_BYTES;
+    threaded = !getenv("QUACK_NO_EARLY") && pthread_create(&th, NULL, acc_creator_main, &cr) == 0;
+    if (!threaded) acc_creator_main(&cr);
+    while (threaded && !atomic_load(&cr.done) && n_early < EARLY_MAX && !qkh_reader_done(rd)) {
+      early_batch *e = &early[n_early];
+      e->seq = early_alloc(early_bytes + QK_TAIL_SLACK);
+      e->qual = early_alloc(early_bytes + QK_TAIL_SLACK);
+      e->off = early_alloc(((size_t)EARLY_READS + 1) * sizeof(uint64_t));
+      if (!e->seq || !e->qual || !e->off) {
+        early_free(e);
+        break;   /* no memory to spare: wait for the accumulators instead */
+      }
+      e->n = qkh_reader_fill(rd, e->seq, e->qual, e->off, early_bytes, EARLY_READS, &e->total, &e->uniform);
+      if (e->n <= 0) {
+        const int64_t n = e->n;
+        early_free(e);
+        if (n == -4) break;   /* a read longer than an early batch: it stays parked for a pinned slot */
+        if (n == 0) continue;
+        pthread_join(th, NULL);
+        made = cr.made;
+        host_fail("%s: out of memory while parsing", path);
+        goto out;
+      }
+      n_early++;
+    }
+    if (threaded) pthread_join(th, NULL);
+    made = cr.made;
+    if (cr.failed) {
+      host_fail("%s", cr.err);
       goto out;
     }
+  }
   t_created = now_s();
+  for (int i = 0; i < n_early; i++) {
+    early_batch *e = &early[i];
+    qk_accum *acc = accs[turn];
+    uint8_t *seq, *qual;
+    uint64_t *offsets, cap_bytes, cap_reads;
+    double ta = now_s(), tb, tc;
+    if (qk_accum_acquire(acc, &seq, &qual, &offsets, &cap_bytes, &cap_reads)) {
+      host_fail("%s", qk_last_error());
+      goto out;
+    }
+    tb = now_s();
+    if (e->total <= cap_bytes && (uint64_t)e->n <= cap_reads) {
+      copy_job jobs[3] = {{seq, e->seq, e->total}, {qual, e->qual, e->total},
+                          {offsets, e->off, e->uniform ? 0 : ((size_t)e->n + 1) * sizeof(uint64_t)}};
+      parallel_copy(jobs, 3);
+      tc = now_s();
+      if (qk_accum_commit(acc, (uint64_t)e->n, e->total, e->uniform == 0, e->uniform)) {
+        host_fail("%s", qk_last_error());
+        goto out;
+      }
+      t_dbg[0] += tb - ta; t_dbg[1] += tc - tb; t_dbg[2] += now_s() - tc;
+    } else if (qk_accum_commit(acc, 0, 0, 0, 0) ||   /* slots smaller than an early batch: the copying feed splits it */
+               (e->uniform ? qk_accum_submit_fixed(acc, e->seq, e->qual, e->uniform, (uint64_t)e->n)
+                           : qk_accum_submit(acc, e->seq, e->qual, e->off, (uint64_t)e->n))) {
+      host_fail("%s", qk_last_error());
+      goto out;
+    }
+    turn = (turn + 1) % n_devices;
+  }
+  /* unmapping 1 GiB costs ~0.1 s (TLB shootdowns across the producer threads): off the critical path */
+  if (n_early && pthread_create(&reaper, NULL, early_reaper_main, early) == 0) reaping = 1;
+  else early_reaper_main(early);
+  t_early = now_s();
+  if (verbose) fprintf(stderr, "[quack] early: acquire %.3f copy %.3f commit %.3f free %.3f\n", t_dbg[0], t_dbg[1], t_dbg[2], t_dbg[3]);
+  n_early_made = n_early;
+  n_early = 0;
   while (!qkh_reader_done(rd)) {
     uint8_t *seq, *qual;
     uint64_t *offsets, cap_bytes, cap_reads, total = 0;
@@ -135,8 +339,19 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
     } else {
       n = qkh_reader_fill(rd, seq, qual, offsets, cap_bytes, cap_reads, &total, &uniform);
     }
+    if (n == -4 && qkh_reader_parked_len(rd) > 0) {
+      /* one read longer than a slot (it is parked on the heap): give this accumulator slots that hold it
+       * with room to spare, and try again */
+      const uint64_t want = qkh_reader_parked_len(rd) + qkh_reader_parked_len(rd) / 4 + 4096;
+      if (qk_accum_commit(acc, 0, 0, 0, 0) || qk_accum_resize_slots(acc, want)) {
+        host_fail("%s: a read of %llu bases does not fit a batch: %s", path,
+                  (unsigned long long)qkh_reader_parked_len(rd), qk_last_error());
+        goto out;
+      }
+      continue;
+    }
     if (n < 0) {
-      host_fail(n == -4 ? "%s: a read exceeds the batch size (raise QUACK_HIP_BATCH_MB)"
+      host_fail(n == -4 ? "%s: a read exceeds the batch size"
                         : "%s: out of memory while parsing", path);
       goto out;
     }
@@ -178,13 +393,25 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       goto out;
     }
   }
+  if (!t_first) t_first = t_parsed;
   if (verbose)
-    fprintf(stderr, "[quack] %s: accumulators %.3f s, first slot %.3f s, parse+submit %.3f s, drain+finish %.3f s\n",
-            path, t_created - t0, t_first - t_created, t_parsed - t_first, now_s() - t_parsed);
+    fprintf(stderr, "[quack] %s: accumulators %.3f s (%d early batches parsed meanwhile, submitted in %.3f s), first slot %.3f s, "
+            "parse+submit %.3f s, drain+finish %.3f s\n",
+            path, t_created - t0, n_early_made, t_early - t_created, t_first - t_early, t_parsed - t_first, now_s() - t_parsed);
   rc = 0;
 out:
-  if (rd) qkh_reader_close(rd);
-  while (made-- > 0) qk_accum_destroy(accs[made]);
+  {
+    const double t_out = now_s();
+    if (reaping) pthread_join(reaper, NULL);
+    else for (int i = 0; i < n_early; i++) early_free(&early[i]);
+    /* the CLI exits right after printing: pinned memory, device buffers, streams and the HIP runtime
+     * itself are left to the operating system (0.16 s of a 0.8 s run otherwise) */
+    if (!(g_process_exits && rc == 0)) {
+      if (rd) qkh_reader_close(rd);
+      while (made-- > 0) qk_accum_destroy(accs[made]);
+    }
+    if (verbose) fprintf(stderr, "[quack] %s: close + destroy %.3f s\n", path, now_s() - t_out);
+  }
   return rc;
 }
 

@@ -67,6 +67,9 @@ int qkh_read_adapters(const char *path, uint32_t *bitset);
 /* devices: list of HIP device ids (n >= 1); batches are dealt round-robin and
  * the per-device tables are summed with one RCCL all-reduce.  On success
  * *bases_out is malloc'd (max_len entries; NULL when max_len == 0). */
+/* CLI only: the process exits (by _exit) right after the results are printed, so a successful
+ * qkh_accumulate_file leaves its accumulators, reader threads and the HIP runtime to the OS. */
+void qkh_process_exits_after_this(int on);
 int qkh_accumulate_file(const char *path, const uint32_t *bitset,
                         const int *devices, int n_devices,
                         qk_base_info **bases_out, uint64_t *max_len,

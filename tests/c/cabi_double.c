@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "quack_hip.h"
 #include "quack_oracle.h"
@@ -37,12 +38,13 @@ struct qk_accum {
   uint32_t *len[2];
   int next, held;
   uint64_t cap_bytes, cap_reads;
-  unsigned long commits, gapped_commits, aligned_commits, strided_commits;
+  unsigned long commits, gapped_commits, aligned_commits, strided_commits, copied_submits, resizes;
 };
 
 int qk_accum_create(qk_accum **out, int device, const uint32_t *bits, uint64_t hint) {
   (void)hint;
   if (device < 0 || device >= 4) return fail(QK_EINVAL, "device out of range");
+  if (getenv("QK_DOUBLE_CREATE_DELAY_MS")) usleep(1000 * (useconds_t)atoi(getenv("QK_DOUBLE_CREATE_DELAY_MS")));   /* a slow HIP start-up */
   qk_accum *a = calloc(1, sizeof *a);
   const char *e = getenv("QK_DOUBLE_SLOT_BYTES");
   oracle_table_init(&a->t);
@@ -66,8 +68,8 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *bits, uint64_t h
 void qk_accum_destroy(qk_accum *a) {
   if (!a) return;
   if (getenv("QK_DOUBLE_VERBOSE"))
-    fprintf(stderr, "[double] commits %lu gapped %lu aligned %lu strided %lu\n", a->commits, a->gapped_commits,
-            a->aligned_commits, a->strided_commits);
+    fprintf(stderr, "[double] commits %lu gapped %lu aligned %lu strided %lu copied %lu resized %lu\n", a->commits, a->gapped_commits,
+            a->aligned_commits, a->strided_commits, a->copied_submits, a->resizes);
   for (int i = 0; i < 2; i++) {
     free(a->seq[i]);
     free(a->qual[i]);
@@ -90,6 +92,26 @@ int qk_accum_acquire(qk_accum *a, uint8_t **seq, uint8_t **qual, uint64_t **off,
   return QK_OK;
 }
 
+int qk_accum_resize_slots(qk_accum *a, uint64_t min_bytes) {
+  if (a->held >= 0) return fail(QK_ESTATE, "a batch is acquired");
+  if (getenv("QK_DOUBLE_NO_RESIZE")) return fail(QK_ENOMEM, "no memory for bigger slots");
+  if (min_bytes <= a->cap_bytes) return QK_OK;
+  a->cap_bytes = min_bytes;
+  a->cap_reads = a->cap_bytes / 32 + 16;
+  for (int i = 0; i < 2; i++) {
+    free(a->seq[i]);
+    free(a->qual[i]);
+    free(a->off[i]);
+    free(a->len[i]);
+    a->seq[i] = malloc(a->cap_bytes + QK_TAIL_SLACK);
+    a->qual[i] = malloc(a->cap_bytes + QK_TAIL_SLACK);
+    a->off[i] = malloc((a->cap_reads + 1) * sizeof(uint64_t));
+    a->len[i] = malloc(a->cap_reads * sizeof(uint32_t));
+  }
+  a->resizes++;
+  return QK_OK;
+}
+
 int qk_accum_slot_lengths(qk_accum *a, uint32_t **lengths) {
   if (a->held < 0) return fail(QK_ESTATE, "no batch acquired");
   *lengths = a->len[a->held];
@@ -108,8 +130,24 @@ int qk_accum_commit(qk_accum *a, uint64_t n, uint64_t total, int offsets_used, u
   if (offsets_used && (a->off[s][0] != 0 || a->off[s][n] != total)) return fail(QK_EINVAL, "bad offsets");
   if (!offsets_used && (uint64_t)read_len * n != total) return fail(QK_EINVAL, "bad fixed batch");
   release(a);
+  if (n == 0) return QK_OK;   /* (an empty batch only touches the slot) */
   a->commits++;
   oracle_accumulate_batch(&a->t, a->seq[s], a->qual[s], offsets_used ? a->off[s] : NULL, n, read_len, a->kmers);
+  return QK_OK;
+}
+
+/* the copying feed: caller-owned memory of any size */
+int qk_accum_submit(qk_accum *a, const uint8_t *seq, const uint8_t *qual, const uint64_t *offsets, uint64_t n) {
+  if (a->held >= 0) return fail(QK_ESTATE, "a batch is acquired");
+  if (n && offsets[0] != 0) return fail(QK_EINVAL, "bad offsets");
+  a->copied_submits++;
+  oracle_accumulate_batch(&a->t, seq, qual, offsets, n, 0, a->kmers);
+  return QK_OK;
+}
+int qk_accum_submit_fixed(qk_accum *a, const uint8_t *seq, const uint8_t *qual, uint32_t read_len, uint64_t n) {
+  if (a->held >= 0) return fail(QK_ESTATE, "a batch is acquired");
+  a->copied_submits++;
+  oracle_accumulate_batch(&a->t, seq, qual, NULL, n, read_len, a->kmers);
   return QK_OK;
 }
 

@@ -70,13 +70,12 @@ def test_python_mirror_validates_batches():
     assert sd.number_of_sequences == want[1] and np.array_equal(sd.bases, want[0])
 
 
-def test_read_longer_than_a_batch_slot_is_reported(monkeypatch, tmp_path):
+def test_read_longer_than_a_batch_slot_grows_the_slots(monkeypatch, tmp_path):
+    """(round 1 reported it as an error; a batch holds whole reads, so the slots now grow:
+    qk_accum_resize_slots, tests/test_gpu_parity.py has the oracle comparison at small sizes)"""
     monkeypatch.setenv("QUACK_HIP_BATCH_MB", "1")
     p = tmp_path / "huge.fq"
     n = (1 << 20) + 100
     p.write_bytes(b"@r\n" + b"A" * n + b"\n+\n" + b"I" * n + b"\n")
-    with pytest.raises(quack_amd.HipUnavailable, match="QUACK_HIP_BATCH_MB"):
-        quack_amd.read_fastq(str(p))
-    monkeypatch.setenv("QUACK_HIP_BATCH_MB", "4")
     sd = quack_amd.read_fastq(str(p))
     assert sd.max_length == n and sd.number_of_sequences == 1 and sd.bases[:, 91].sum() == n

@@ -464,6 +464,25 @@ def test_software_pipelined_variants_are_equivalent(monkeypatch, unroll, pipe):
         assert_same(hip_table(seq, qual, off, kmers_bits=bits), ob.accumulate_batch(seq, qual, off, kmers=k))
 
 
+def test_reads_longer_than_a_slot_make_the_slots_grow(monkeypatch, tmp_path):
+    """64 KiB slots and reads of up to 300 kb: the copying feed and the host feed both move to bigger
+    slots (qk_accum_resize_slots) instead of failing — the reference has no length limit"""
+    monkeypatch.setenv("QUACK_HIP_BATCH_KB", "64")
+    seq, qual, off = synth.ragged(60, 100, 300000, seed=77)
+    want = ob.accumulate_batch(seq, qual, off)
+    assert_same(hip_table(seq, qual, off), want)
+    L = 70000
+    fs, fq = synth.fixed(5, L, seed=5)
+    assert_same(hip_table(fs, fq, read_len=L), ob.accumulate_batch(fs, fq, read_len=L))
+    path = tmp_path / "long.fq"
+    with open(path, "wb") as f:
+        for i in range(len(off) - 1):
+            a, b = int(off[i]), int(off[i + 1])
+            f.write(b"@r%d\n" % i + seq[a:b].tobytes() + b"\n+\n" + qual[a:b].tobytes() + b"\n")
+    sd = quack_amd.read_fastq(str(path))
+    assert_same((sd.bases, sd.number_of_sequences), want)
+
+
 def test_empty_inputs():
     with quack_amd.Accumulator(0) as acc:
         acc.submit(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))

@@ -31,9 +31,14 @@ def quack_double(tmp_path_factory):
     return exe
 
 
-def run(exe, argv, **env):
+def run(exe, argv, early=False, **env):
+    """early=False: no reads are parsed while the accumulators start (QUACK_NO_EARLY), so that every batch
+    goes through the pinned slots whose handling these tests are about"""
+    base = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", QUACK_FULL_TEARDOWN="1")
+    if not early:
+        base["QUACK_NO_EARLY"] = "1"
     return subprocess.run([exe] + argv, capture_output=True, cwd=os.path.join(cases.G, "inputs"),
-                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", **env), timeout=300)
+                          env=dict(base, **env), timeout=300)
 
 
 @pytest.mark.parametrize("name,argv", cases.load(), ids=[c[0] for c in cases.load()])
@@ -61,9 +66,9 @@ def test_long_reads_switch_to_cache_line_batches(quack_double, tmp_path):
     b = run(quack_double, ["-u", str(fq)], QK_DOUBLE_VERBOSE="1", QUACK_NO_ALIGN="1")
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 1000
     stats = lambda r: [int(t) for t in r.stderr.decode().split("[double]")[1].split() if t.isdigit()]
-    commits, gapped, aligned, strided = stats(a)
+    commits, gapped, aligned, strided = stats(a)[:4]
     assert commits > 5 and gapped == aligned == commits - 1 and strided == 0, a.stderr     # all but the first batch
-    assert stats(b)[1:] == [0, 0, 0]
+    assert stats(b)[1:4] == [0, 0, 0]
 
 
 def write_fastq(path, lens, g):
@@ -90,7 +95,7 @@ def test_trimmed_short_reads_switch_to_strided_batches(quack_double, tmp_path):
         b = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], QK_DOUBLE_VERBOSE="1", QUACK_NO_STRIDE="1", **extra)
         assert a.returncode == 0 and b.returncode == 0, a.stderr[-2000:]
         assert a.stdout == b.stdout and len(a.stdout) > 1000
-        commits, gapped, aligned, strided = stats(a)
+        commits, gapped, aligned, strided = stats(a)[:4]
         assert gapped == 0 and strided >= commits - 6 and strided > 10, a.stderr
         assert stats(b)[3] == 0
 
@@ -104,9 +109,54 @@ def test_equal_length_reads_stay_fixed_length_batches(quack_double, tmp_path):
     assert [int(t) for t in a.stderr.decode().split("[double]")[1].split() if t.isdigit()][3] == 0
 
 
-def test_a_read_larger_than_a_slot_is_an_error_not_a_truncation(quack_double):
-    r = run(quack_double, ["-u", "long40.fq.gz"], QK_DOUBLE_SLOT_BYTES="3000")
-    assert r.returncode == 1 and r.stdout == b"" and b"exceeds the batch size" in r.stderr
+def test_reads_parsed_while_the_accumulators_start_up(quack_double, tmp_path):
+    """a slow HIP start-up (here: the double sleeps in qk_accum_create): the tokenizer fills heap batches
+    meanwhile and hands them to the copying feed; same SVG, also when the process exits without teardown
+    (the CLI's default) and when a read is too long for an early batch"""
+    g = np.random.default_rng(12)
+    fq = tmp_path / "early.fq"
+    write_fastq(fq, g.integers(30, 200, 30000), g)
+    stats = lambda r: [int(t) for t in r.stderr.decode().split("[double]")[1].split() if t.isdigit()]
+    want = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], QK_DOUBLE_VERBOSE="1")
+    assert want.returncode == 0 and stats(want)[4] == 0
+    for extra in ({}, {"QUACK_DEVICES": "0,1,2"}):
+        got = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], early=True, QK_DOUBLE_CREATE_DELAY_MS="300",
+                  QK_DOUBLE_VERBOSE="1", **extra)
+        assert got.returncode == 0, got.stderr[-2000:]
+        assert got.stdout == want.stdout
+        copied = sum(int(l.split("copied")[1].split()[0]) for l in got.stderr.decode().splitlines() if l.startswith("[double]"))
+        assert copied >= 1, got.stderr               # early batches went through the copying feed
+    env = dict(os.environ, QK_DOUBLE_CREATE_DELAY_MS="200")
+    fast = subprocess.run([quack_double, "-u", str(fq), "-a", "adapters.fa"], capture_output=True,
+                          cwd=os.path.join(cases.G, "inputs"), env=env, timeout=300)
+    assert fast.returncode == 0 and fast.stdout == want.stdout
+    # a read longer than an early batch (shrunk to 10 kB here) waits, parked, for a pinned slot
+    big = tmp_path / "big.fq"
+    with open(big, "wb") as f:
+        f.write(open(fq, "rb").read()[:200000].rsplit(b"\n@", 1)[0] + b"\n")
+        f.write(b"@big\n" + b"A" * 20000 + b"\n+\n" + b"I" * 20000 + b"\n")
+        f.write(open(fq, "rb").read())
+    a = run(quack_double, ["-u", str(big)], early=True, QK_DOUBLE_CREATE_DELAY_MS="300", QUACK_EARLY_BYTES="10000",
+            QK_DOUBLE_VERBOSE="1", QUACK_VERBOSE="1")
+    b = run(quack_double, ["-u", str(big)])
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 1000
+    import re
+    n_early = int(re.search(rb"\((\d+) early batches", a.stderr).group(1))
+    commits = int(a.stderr.decode().split("[double]")[1].split()[1])
+    assert 1 <= n_early < commits, a.stderr            # early batches (they fit a slot here: copied into it), then the rest
+
+
+def test_a_read_larger_than_a_slot_gets_bigger_slots(quack_double):
+    """a batch holds whole reads: when one does not fit, the accumulator's slots grow (qk_accum_resize_slots) —
+    the reference has no length limit (quack.c:194-198) — and if they cannot, that is an error, not a truncation"""
+    want = cases.golden_svg("long40")
+    r = run(quack_double, ["-u", "long40.fq.gz"], QK_DOUBLE_SLOT_BYTES="3000", QK_DOUBLE_VERBOSE="1")
+    assert r.returncode == 0 and r.stdout == want, r.stderr[-2000:]
+    assert int(r.stderr.decode().split("resized")[1].split()[0]) >= 1
+    r = run(quack_double, ["-u", "long40.fq.gz"], QK_DOUBLE_SLOT_BYTES="3000", QUACK_DEVICES="0,1")
+    assert r.returncode == 0 and r.stdout == want
+    r = run(quack_double, ["-u", "long40.fq.gz"], QK_DOUBLE_SLOT_BYTES="3000", QK_DOUBLE_NO_RESIZE="1")
+    assert r.returncode == 1 and r.stdout == b"" and b"does not fit a batch" in r.stderr
 
 
 # ---------------------------------------------------------------- damaged gzip trailers (CRC-32 / ISIZE)
