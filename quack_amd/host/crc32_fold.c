@@ -12,6 +12,7 @@
  * zlib in tests/test_inflate.py.
  */
 #include <stddef.h>
+#include <stdatomic.h>
 #include <stdint.h>
 #include <zlib.h>
 
@@ -95,9 +96,14 @@ __attribute__((target("pclmul,sse4.1"))) static uint32_t crc32_fold_blocks(uint3
 }
 
 static int have_clmul(void) {
-  static int known = -1;
-  if (known < 0) known = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
-  return known;
+  /* (asked by every producer thread: an atomic, although all of them would store the same value) */
+  static _Atomic int known = -1;
+  int k = atomic_load_explicit(&known, memory_order_relaxed);
+  if (k < 0) {
+    k = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    atomic_store_explicit(&known, k, memory_order_relaxed);
+  }
+  return k;
 }
 #endif
 

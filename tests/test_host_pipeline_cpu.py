@@ -227,3 +227,21 @@ def test_damaged_member_in_the_middle_of_many(quack_double, tmp_path, kind):
             got = run(quack_double, ["-u", str(path)], **env)
             assert got.returncode == 0, got.stderr[-1000:]
             assert got.stdout == want.stdout, (kind, victim, env)
+
+
+def test_pipeline_threads_under_tsan(tmp_path):
+    """ThreadSanitizer build of the whole host on the test double: the accumulator-creator thread beside the
+    tokenizer, the copy threads and the reaper of the early batches, the two mate threads of a pair, several
+    accumulators per file"""
+    exe = str(tmp_path / "quack_double_tsan")
+    subprocess.check_call(
+        ["gcc", "-O1", "-g", "-std=c11", "-D_DEFAULT_SOURCE", "-D_POSIX_C_SOURCE=200809L", "-pthread", "-fsanitize=thread",
+         "-I" + os.path.join(cases.ROOT, "include"), "-I" + HOST, "-I" + os.path.join(cases.ROOT, "oracle"),
+         "-o", exe] + SRC + ["-lz", "-lm"])
+    base = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66", QUACK_FULL_TEARDOWN="1", QK_DOUBLE_CREATE_DELAY_MS="150")
+    for name, env in (("paired_adapters_named", {}), ("ragged100_adapters", {"QUACK_DEVICES": "0,1,2", "QUACK_EARLY_BYTES": "3000"}),
+                      ("long40", {"QK_DOUBLE_SLOT_BYTES": "3000"}), ("uniform100_gz", {"QUACK_THREADS": "4"})):
+        argv = dict(cases.load())[name]
+        r = subprocess.run([exe] + argv, capture_output=True, cwd=os.path.join(cases.G, "inputs"), env=dict(base, **env), timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-4000:])
+        assert r.stdout == cases.golden_svg(name) and b"ThreadSanitizer" not in r.stderr
