@@ -120,7 +120,8 @@ def main():
         if sq_derived:
             d = sq_derived
             f.write("\nSQ counters (separate passes): %.1f VALU, %.1f SALU, %.1f LDS, %.2f VMEM-read instructions per wave and "
-                    "8-position chunk; VALU busy %.0f %% of the SIMD cycles (%.0f kernel cycles = %.2f GHz); LDS bank-conflict "
+                    "8-position chunk; VALU instructions x 4 cycles = %.0f %% of the SIMD cycles — an upper bound: SQ_ACTIVE_INST_VALU counts "
+                    "instructions, and half of the integer ones issue in 2 (tools/instr_rate.hip) — (%.0f kernel cycles = %.2f GHz); LDS bank-conflict "
                     "share %.0f %%; waves waiting to issue %.0f %% of their cycles\n"
                     % (d["valu_insts_per_wave_chunk"], d["salu_insts_per_wave_chunk"], d["lds_insts_per_wave_chunk"],
                        d["vmem_rd_insts_per_wave_chunk"], 100 * (d["valu_busy_share_of_simd_cycles"] or 0), d["kernel_cycles"],
