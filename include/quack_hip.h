@@ -188,6 +188,8 @@ int qk_accum_finish(qk_accum *acc, qk_base_info *out, uint64_t cap_positions,
 /* ---- timing hooks (bench.py / kbench) --------------------------------- */
 /* Average duration in ms of the histogram kernel launches recorded since the
  * last reset, measured with hipEvents on the launch stream. */
+/* on = N > 1: only every Nth batch is timed (the events themselves cost ~10 us of stream time per
+ * batch; a caller that also takes the wall clock of the whole run samples) */
 int qk_accum_timing_enable(qk_accum *acc, int on);
 int qk_accum_timing_read(qk_accum *acc, double *total_ms, uint64_t *launches);
 /* Same, plus the time of ALL kernels of the batches (reach pre-pass, length

@@ -240,7 +240,8 @@ class Accumulator:
         _check(self._L.qk_accum_import_table(self._h, d_src.data_ptr(), max_len, stream))
 
     def timing(self, on=True):
-        _check(self._L.qk_accum_timing_enable(self._h, 1 if on else 0))
+        """on: False / True, or N > 1 = HIP events around every Nth batch only"""
+        _check(self._L.qk_accum_timing_enable(self._h, int(on)))
 
     def timing_read(self):
         ms, n = ctypes.c_double(), ctypes.c_uint64()

@@ -115,7 +115,8 @@ struct qk_accum {
   // tuning
   int threads = 1024, unroll = 0, pipe = 0, tile = 0, wgs_per_cu = 0;   // 0 = automatic
   // timing
-  bool timing = false;
+  int timing = 0;                   // 0 off; N: events around every Nth batch
+  uint64_t timing_seq = 0;
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> event_pool;
   double timing_ms = 0, timing_batch_ms = 0;
@@ -462,7 +463,10 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   if (strided && !pl.aligned) return fail(QK_EINVAL, "strided batches run with the planner's own launch geometry only");
   if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));
   TimedLaunch tl{};
-  if (a->timing) {
+  // (events around a launch cost ~10 us of stream time: a caller that also measures its own wall
+  // clock asks for every Nth batch only)
+  const bool timed = a->timing > 0 && (a->timing_seq++ % (uint64_t)a->timing) == 0;
+  if (timed) {
     tl.t0 = get_event(a);
     tl.t1 = get_event(a);
     if (!tl.t0 || !tl.t1) return fail(QK_EHIP, "hipEventCreate failed");
@@ -575,17 +579,17 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.replicas = pl.replicas;
   hp.halo = pl.halo;
 
-  if (a->timing) QK_HIP(hipEventRecord(tl.t0, st));
+  if (timed) QK_HIP(hipEventRecord(tl.t0, st));
   if (pl.fused_adapters) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
   rc = launch_hist(a, hp, pl, d_off == nullptr, g_ablation_mode, pl.fused_adapters, st, strided);
   if (rc) return rc;
-  if (a->timing) QK_HIP(hipEventRecord(tl.t1, st));
+  if (timed) QK_HIP(hipEventRecord(tl.t1, st));
   if (a->adapters) {
     // fused: the histogram pass already left first_hit[]; otherwise scan now
     rc = pl.fused_adapters ? qk::launch_adapter_count(hp, a->n_cu, st) : qk::launch_adapter_scan(hp, a->n_cu, st);
     if (rc) return fail(QK_EHIP, "adapter kernels failed: %s", hipGetErrorString((hipError_t)rc));
   }
-  if (a->timing) {
+  if (timed) {
     if (tl.b1 != tl.t1) QK_HIP(hipEventRecord(tl.b1, st));
     a->timed.push_back(tl);
   }
@@ -950,6 +954,7 @@ int qk_accum_resize_slots(qk_accum *a, uint64_t min_bytes) {
   }
   a->cap_bytes = round_up(min_bytes, 1u << 20);
   a->cap_reads = a->cap_bytes / 32 + 1024;
+  a->order_stream = nullptr;   // (a new slot stream may get a destroyed one's handle: the next launch waits for order_ev)
   return QK_OK;
 }
 
@@ -1403,7 +1408,8 @@ int qk_accum_finish(qk_accum *a, qk_base_info *out, uint64_t cap_positions,
 
 int qk_accum_timing_enable(qk_accum *a, int on) {
   if (!a) return fail(QK_EINVAL, "acc is NULL");
-  a->timing = on != 0;
+  a->timing = on < 0 ? 0 : on;
+  a->timing_seq = 0;
   a->timing_ms = 0;
   a->timing_batch_ms = 0;
   a->timing_launches = 0;
