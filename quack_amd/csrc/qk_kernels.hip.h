@@ -97,6 +97,7 @@ struct HistParams {
   const unsigned long long *tile_prefix;   // [n_tiles + 1] reads of the tiles before t, or NULL (t * n_reads)
   uint32_t static_split;
   uint32_t no_adapters;         // kmers == NULL semantics (quack.c:210,215)
+  uint32_t count_in_kernel;     // fused adapters, one tile: hist_kernel resets first_hit[] and takes the kmer_count itself
   // exact LDS-resident membership table the queued candidates are checked against (0: the
   // global 2^20-bit table — huge adapter files, or no room): 2^bucket_log2 buckets of eight
   // u16 remainders
@@ -183,7 +184,7 @@ constexpr uint32_t kCandCap = 96;                       // entries per wave: dra
 constexpr uint32_t kCandWords = 16u * kCandCap * 2u;    // 16 waves x 96 entries x 8 bytes = 12 KiB
 inline size_t hist_lds_bytes(uint32_t ch, uint32_t replicas, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false,
                              uint32_t stage_reads = kStageReads) {
-  return ((size_t)kQRows * hist_row_dwords(ch, replicas) + 5u * 8u * ch + 4u + (adapt ? kFusedFilterWords + kCandWords : 0u)) * sizeof(uint32_t) +
+  return ((size_t)kQRows * hist_row_dwords(ch, replicas) + (adapt ? 6u : 5u) * 8u * ch + 4u + (adapt ? kFusedFilterWords + kCandWords : 0u)) * sizeof(uint32_t) +
          (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)stage_reads * (adapt ? 12 : 8) : 0);
 }
 
@@ -308,7 +309,8 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   const uint32_t hist_words = kQRows * RD;
   uint32_t *lds_base = lds + hist_words;  // [4][TP]
   uint32_t *lds_len = lds_base + 4u * TP;
-  uint32_t *lds_misc = lds_len + TP;      // [0] reads longer than 10, [1] next item
+  uint32_t *lds_kmer = lds_len + TP;      // ADAPT: kmer_count of the tile (count_in_kernel)
+  uint32_t *lds_misc = lds_kmer + (ADAPT ? TP : 0u);      // [0] reads longer than 10, [1] next item
   uint32_t *lds_filter = lds_raw;         // ADAPT only
   const uint8_t *filt8 = reinterpret_cast<const uint8_t *>(lds_raw);   // == LDS byte 0, see lds_abs_u8
   (void)filt8;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   };
 
   auto zero_lds = [&]() {
-    for (uint32_t i = tid; i < hist_words + 5u * TP + 1u; i += T) lds[i] = 0;
+    for (uint32_t i = tid; i < hist_words + (ADAPT ? 6u : 5u) * TP + 1u; i += T) lds[i] = 0;
   };
 
   // ---- flush: LDS -> planar u64 table; zero counters are skipped.  One wave
@@ -462,6 +464,13 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
           atomicAdd(&p.table[(uint64_t)kRowLength * TL + P0 + pp], (unsigned long long)c);
       }
     }
+    if (ADAPT && p.count_in_kernel) {
+      for (uint32_t pp = tid; pp < TP; pp += T) {
+        const uint32_t c = lds_kmer[pp];
+        if (c != 0 && P0 + pp < p.table_len)
+          atomicAdd(&p.table[(uint64_t)kRowKmer * TL + P0 + pp], (unsigned long long)c);
+      }
+    }
     if (tile == 0) {
       if (FAST_FIXED) {
         if (tid == 0 && fixed_reads != 0) {
@@ -492,6 +501,17 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
     if (r_end > list_len) r_end = list_len;
     const uint32_t slice_reads = r_end > r_begin ? (uint32_t)(r_end - r_begin) : 0u;
     if (FIXED && tile == 0) fixed_reads += slice_reads;
+    // One tile: every read of the slice is this workgroup's alone, so the per-read first-hit words need no
+    // pass of their own before the launch and no counting kernel behind it (adapter_count_kernel) —
+    // 45 us of a 1.5 ms step on 10M x 300.  Reset here, count below, both with device-coherent
+    // accesses: the atomicMin of the drain happens at the memory side.
+    if (ADAPT && p.count_in_kernel) {
+      for (uint32_t i = tid; i < slice_reads; i += T)
+        __hip_atomic_store(&p.first_hit[r_begin + i], kNoHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (every access to these words is an agent-scope atomic and the barrier orders them: no __threadfence —
+      // on this part it writes back and invalidates the XCD's L2 under 31 other streaming workgroups, +12 % kernel time)
+      __syncthreads();
+    }
     // 32-bit byte offsets relative to a 4-byte-aligned, workgroup-uniform base
     uint64_t slice_base = 0;
     // (sorted: the slice's reads lie anywhere in the batch, which is < 4 GiB then: base 0)
@@ -928,6 +948,27 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
         }
       }
       if (ADAPT && cand_n) drain_candidates();   // the entries refer to this pass's read list
+    }
+    if (ADAPT && p.count_in_kernel) {
+      // quack.c:211-217: i ends one past the first window found; counted iff i < l
+      __syncthreads();
+      // (eight loads in flight per thread: they bypass the caches, and one round trip per read — 38 in a row
+      // for a slice of 39k reads — cost 0.1 ms at the end of every workgroup)
+      for (uint32_t i0 = tid; i0 < slice_reads; i0 += 8u * T) {
+        uint32_t fh[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t i = i0 + (uint32_t)k * T;
+          fh[k] = i < slice_reads ? __hip_atomic_load(&p.first_hit[r_begin + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kNoHit;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (fh[k] == kNoHit) continue;
+          const uint64_t r = r_begin + i0 + (uint32_t)k * T;
+          const uint32_t len = (FIXED && !SV) ? p.read_len : (p.lengths ? p.lengths[r] : (uint32_t)(p.offsets[r + 1] - p.offsets[r]));
+          if (fh[k] + 1u < len && fh[k] + 1u < TP) lds_add(lds_kmer, 4u * (fh[k] + 1u), 1u);
+        }
+      }
     }
     if (MODE == 0 || MODE == 3) spill();
     return slice_reads;

@@ -579,12 +579,14 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.replicas = pl.replicas;
   hp.halo = pl.halo;
 
+  // one tile: the histogram kernel resets first_hit[] and takes the kmer_count of its own reads
+  hp.count_in_kernel = pl.fused_adapters && pl.n_tiles == 1 && !getenv("QUACK_HIP_SEPARATE_COUNT");
   if (timed) QK_HIP(hipEventRecord(tl.t0, st));
-  if (pl.fused_adapters) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
+  if (pl.fused_adapters && !hp.count_in_kernel) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
   rc = launch_hist(a, hp, pl, d_off == nullptr, g_ablation_mode, pl.fused_adapters, st, strided);
   if (rc) return rc;
   if (timed) QK_HIP(hipEventRecord(tl.t1, st));
-  if (a->adapters) {
+  if (a->adapters && !hp.count_in_kernel) {
     // fused: the histogram pass already left first_hit[]; otherwise scan now
     rc = pl.fused_adapters ? qk::launch_adapter_count(hp, a->n_cu, st) : qk::launch_adapter_scan(hp, a->n_cu, st);
     if (rc) return fail(QK_EHIP, "adapter kernels failed: %s", hipGetErrorString((hipError_t)rc));
