@@ -146,6 +146,21 @@ def test_reads_parsed_while_the_accumulators_start_up(quack_double, tmp_path):
     assert 1 <= n_early < commits, a.stderr            # early batches (they fit a slot here: copied into it), then the rest
 
 
+def test_uncompressed_files_are_read_by_a_worker_pool(quack_double, tmp_path):
+    """plain files of two blocks (8 MiB) and more: a dispatcher hands 4 MiB file ranges to workers that pread() them
+    and index their lines; same SVG as the one-thread read(2) producer, also when records straddle every block edge"""
+    g = np.random.default_rng(21)
+    fq = tmp_path / "plain.fq"
+    write_fastq(fq, g.integers(40, 160, 70000), g)
+    assert os.path.getsize(fq) > 3 * (4 << 20)
+    want = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], QUACK_NO_PLAIN_POOL="1", QK_DOUBLE_SLOT_BYTES="3000000")
+    assert want.returncode == 0 and len(want.stdout) > 1000
+    for env in ({}, {"QUACK_THREADS": "2"}, {"QUACK_DEVICES": "0,1"}):
+        got = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], QK_DOUBLE_SLOT_BYTES="3000000", QUACK_VERBOSE="1", **env)
+        assert got.returncode == 0, got.stderr[-2000:]
+        assert got.stdout == want.stdout, env
+
+
 def test_a_read_larger_than_a_slot_gets_bigger_slots(quack_double):
     """a batch holds whole reads: when one does not fit, the accumulator's slots grow (qk_accum_resize_slots) —
     the reference has no length limit (quack.c:194-198) — and if they cannot, that is an error, not a truncation"""
@@ -239,6 +254,13 @@ def test_pipeline_threads_under_tsan(tmp_path):
          "-I" + os.path.join(cases.ROOT, "include"), "-I" + HOST, "-I" + os.path.join(cases.ROOT, "oracle"),
          "-o", exe] + SRC + ["-lz", "-lm"])
     base = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66", QUACK_FULL_TEARDOWN="1", QK_DOUBLE_CREATE_DELAY_MS="150")
+    g = np.random.default_rng(22)
+    plain = tmp_path / "plain9.fq"
+    write_fastq(plain, g.integers(100, 200, 30000), g)      # > 8 MiB: the plain-file worker pool
+    want_plain = subprocess.run([exe, "-u", str(plain)], capture_output=True, env=dict(base, QUACK_NO_PLAIN_POOL="1"), timeout=600)
+    got_plain = subprocess.run([exe, "-u", str(plain)], capture_output=True, env=base, timeout=600)
+    assert want_plain.returncode == 0 and got_plain.returncode == 0, got_plain.stderr[-4000:]
+    assert got_plain.stdout == want_plain.stdout and b"ThreadSanitizer" not in got_plain.stderr
     for name, env in (("paired_adapters_named", {}), ("ragged100_adapters", {"QUACK_DEVICES": "0,1,2", "QUACK_EARLY_BYTES": "3000"}),
                       ("long40", {"QK_DOUBLE_SLOT_BYTES": "3000"}), ("uniform100_gz", {"QUACK_THREADS": "4"})):
         argv = dict(cases.load())[name]
