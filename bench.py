@@ -81,7 +81,7 @@ def parse_args():
                     help="auto: cfg2 at N=1 (the headline), cfg4's per-GPU share at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="N=1: skip the cfg3 / cfg5 lines")
-    ap.add_argument("--also-steps", type=int, default=20)
+    ap.add_argument("--also-steps", type=int, default=50)
     # rehearsal on a one-GPU box: several ranks share one device and the table
     # exchange goes through gloo (the driver's runs use the defaults: nccl = RCCL)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -507,7 +507,7 @@ def main():
                 w2 = dict(WORKLOADS[nm])
                 bits2, ads2 = synthetic_adapter_bits(np) if w2["adapters"] else (None, None)
                 bb = make_batch(torch, np, w2, seed={"cfg3": 3, "cfg5": 6, "trimmed": 7}[nm], device=device, ads=ads2)
-                el, kms2, bms2, l2, _ = time_workload(torch, quack_amd, w2, bb, local, bits2, args.also_steps, 3)
+                el, kms2, bms2, l2, _ = time_workload(torch, quack_amd, w2, bb, local, bits2, args.also_steps, 15)
                 entry = {"workload": w2["label"], "steps": args.also_steps, "value": args.also_steps * bb["total"] / el,
                          "unit": "bases/s", "ms_per_step": el / args.also_steps * 1e3,
                          "roofline": roofline_of(alg_bytes_of(bb), kms2, bms2, l2, traffic_tab.get(nm))}
