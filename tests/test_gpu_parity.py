@@ -483,6 +483,28 @@ def test_reads_longer_than_a_slot_make_the_slots_grow(monkeypatch, tmp_path):
     assert_same((sd.bases, sd.number_of_sequences), want)
 
 
+def test_timing_hooks_sample_every_nth_batch():
+    """qk_accum_timing_enable(acc, N): HIP events around every Nth batch only; the tables are not affected"""
+    seq, qual = synth.fixed(20000, 100, seed=8)
+    want = ob.accumulate_batch(np.tile(seq, 9), np.tile(qual, 9), read_len=100)
+    with quack_amd.Accumulator(0) as acc:
+        acc.timing(4)
+        for _ in range(9):
+            acc.submit_fixed(seq, qual, 100)
+        acc.sync()
+        hist_ms, batch_ms, launches = acc.timing_read_batch()
+        assert launches == 3 and 0 < hist_ms <= batch_ms + 1e-6      # batches 0, 4, 8
+        acc.timing(True)
+        acc.submit_fixed(seq, qual, 100)
+        acc.sync()
+        assert acc.timing_read_batch()[2] == 1
+        acc.timing(False)
+        sd = acc.finish()
+    want10 = ob.accumulate_batch(np.tile(seq, 10), np.tile(qual, 10), read_len=100)
+    assert_same((sd.bases, sd.number_of_sequences), want10)
+    del want
+
+
 def test_empty_inputs():
     with quack_amd.Accumulator(0) as acc:
         acc.submit(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
