@@ -187,7 +187,6 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
   qkh_reader *rd = NULL;
   int rc = -1, turn = 0, made = 0, long_reads = 0, n_early = 0, n_early_made;
   early_batch early[EARLY_MAX];
-  double t_dbg[4] = {0, 0, 0, 0};
   pthread_t reaper;
   int reaping = 0;
   memset(early, 0, sizeof early);
@@ -256,22 +255,18 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
     qk_accum *acc = accs[turn];
     uint8_t *seq, *qual;
     uint64_t *offsets, cap_bytes, cap_reads;
-    double ta = now_s(), tb, tc;
     if (qk_accum_acquire(acc, &seq, &qual, &offsets, &cap_bytes, &cap_reads)) {
       host_fail("%s", qk_last_error());
       goto out;
     }
-    tb = now_s();
     if (e->total <= cap_bytes && (uint64_t)e->n <= cap_reads) {
       copy_job jobs[3] = {{seq, e->seq, e->total}, {qual, e->qual, e->total},
                           {offsets, e->off, e->uniform ? 0 : ((size_t)e->n + 1) * sizeof(uint64_t)}};
       parallel_copy(jobs, 3);
-      tc = now_s();
       if (qk_accum_commit(acc, (uint64_t)e->n, e->total, e->uniform == 0, e->uniform)) {
         host_fail("%s", qk_last_error());
         goto out;
       }
-      t_dbg[0] += tb - ta; t_dbg[1] += tc - tb; t_dbg[2] += now_s() - tc;
     } else if (qk_accum_commit(acc, 0, 0, 0, 0) ||   /* slots smaller than an early batch: the copying feed splits it */
                (e->uniform ? qk_accum_submit_fixed(acc, e->seq, e->qual, e->uniform, (uint64_t)e->n)
                            : qk_accum_submit(acc, e->seq, e->qual, e->off, (uint64_t)e->n))) {
@@ -284,7 +279,6 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
   if (n_early && pthread_create(&reaper, NULL, early_reaper_main, early) == 0) reaping = 1;
   else early_reaper_main(early);
   t_early = now_s();
-  if (verbose) fprintf(stderr, "[quack] early: acquire %.3f copy %.3f commit %.3f free %.3f\n", t_dbg[0], t_dbg[1], t_dbg[2], t_dbg[3]);
   n_early_made = n_early;
   n_early = 0;
   while (!qkh_reader_done(rd)) {
