@@ -1,0 +1,14 @@
+#!/bin/bash
+# Run ON THE GPU BOX: config-2 / config-3 shaped batches (10M reads) at the common Illumina read lengths.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+for w in cfg2 cfg3; do
+  for L in 36 50 76 100 125 150 200 250 300; do
+    python bench.py --workload $w --read-len $L --no-also --no-cpu-baseline --steps 100 --warmup 30 2>/dev/null | tail -1 > /tmp/ls.json
+    python - "$w" "$L" <<'PY'
+import json, sys
+d = json.load(open("/tmp/ls.json")); r = d["roofline"]
+print("%s L=%-3s  %.3f Tbases/s  step %.4f ms  kernel %.4f ms  frac %.3f" % (sys.argv[1], sys.argv[2], d["value"] / 1e12, d["ms_per_step"], r["kernel_ms"], r["frac"]))
+PY
+  done
+done
