@@ -4,12 +4,14 @@
 set -e
 other=$1; shift
 cp quack_amd/libquack_hip.so /tmp/ab_A.so
+# whatever happens (a failing B run under set -e, Ctrl-C): the product library is put back
+trap 'cp /tmp/ab_A.so quack_amd/libquack_hip.so' EXIT
 cp "$other" /tmp/ab_B.so
 for rep in $(seq 1 ${AB_REPS:-2}); do
   for v in A B; do
     cp /tmp/ab_$v.so quack_amd/libquack_hip.so
     for w in "$@"; do
-      python bench.py --workload $w --no-also --no-cpu $AB_ARGS 2>/dev/null | tail -1 > /tmp/ab_line.json
+      python bench.py --workload $w --no-also --no-cpu-baseline $AB_ARGS 2>/dev/null | tail -1 > /tmp/ab_line.json
       python - "$v" "$w" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab_line.json"))
@@ -18,4 +20,3 @@ PY
     done
   done
 done
-cp /tmp/ab_A.so quack_amd/libquack_hip.so

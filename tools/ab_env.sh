@@ -2,6 +2,7 @@
 # like ab_bench.sh, but the B build also gets environment variables: tools/ab_env.sh <other.so> "<VAR=..>" <workload> [bench args]
 other=$1; benv=$2; w=$3; shift 3
 cp quack_amd/libquack_hip.so /tmp/ab_A.so
+trap 'cp /tmp/ab_A.so quack_amd/libquack_hip.so' EXIT   # also on Ctrl-C or a failing run
 cp "$other" /tmp/ab_B.so
 for rep in 1 2; do
   for v in A B; do
@@ -18,4 +19,3 @@ except Exception:
 PY
   done
 done
-cp /tmp/ab_A.so quack_amd/libquack_hip.so
