@@ -45,3 +45,16 @@ EXACT_100 = {"uniform100", "uniform100_gz", "uniform100_named", "uniform100_adap
              "uniform100_longflags", "adapter100", "adapter100_noadapters", "crlf100", "multiline100",
              "truncated100", "nonewline100", "phred64_100", "unpaired_wins_over_half_pair"}
 BINNED = {"long40", "long40_adapters"}
+
+
+def raw_table(name, panel=0):
+    """the REFERENCE's raw `bases[]` (quack.c:223-226) for a golden case: [max_length][97] u64, made by
+    oracle/make_raw_goldens.sh from the unmodified reference binary (LD_PRELOAD observer oracle/ref_peek.c)"""
+    import numpy as np
+    with gzip.open(os.path.join(G, "raw", "%s.%d.u64.gz" % (name, panel))) as f:
+        return np.frombuffer(f.read(), dtype="<u8").reshape(-1, 97)
+
+
+# cases whose inputs leave quack.c's defined domain (a quality byte above '{' indexes past scores[91],
+# quack.c:203-204: the reference's table is then whatever the aliasing did); none today
+RAW_UNDEFINED = set()

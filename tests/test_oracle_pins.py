@@ -83,6 +83,27 @@ def test_oracle_against_reference_svg(name, argv):
             assert (raw[:, :91].sum(axis=1) == 100).all()
 
 
+@pytest.mark.parametrize("name,argv", cases.load(), ids=[c[0] for c in cases.load()])
+def test_oracle_against_reference_raw_counters(name, argv):
+    """every counter of every position, incl. what draw() never shows: bases[10].kmer_count without -a
+    (quack.c:215, kmers == NULL) and the score bins outside the drawn range (quack.c:326-332)"""
+    tables, _ = _tables_for(argv)
+    for panel, (bases, n_reads) in enumerate(tables):
+        want = cases.raw_table(name, panel)
+        assert bases.shape == want.shape
+        np.testing.assert_array_equal(bases, want)
+        assert int(want[:, 95].sum()) == n_reads          # every read has a last base (no empty reads in the goldens)
+
+
+def test_the_undrawn_kmer_counter_is_the_references():
+    """without -a every read longer than 10 counts at bases[10].kmer_count (quack.c:206-217 with kmers == NULL):
+    read off the reference's own table"""
+    raw = cases.raw_table("uniform100")
+    assert raw[10, 96] == 100 and raw[:, 96].sum() == 100
+    raw = cases.raw_table("kat")
+    assert raw[10, 96] == 4 and raw[:, 96].sum() == 4
+
+
 def test_tokenizer_corner_cases_agree_with_plain_layout():
     """crlf / truncated / no-final-newline files carry the same 100 records:
     the reference draws identical SVGs for them, so must the oracle's tables."""
