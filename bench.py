@@ -15,19 +15,26 @@ synthetic reads that is already resident in HBM.
   N = 1   the configuration the metric is quoted on: 10M-read synthetic 150 bp
           FASTQ, no adapters (BASELINE.json configs[1]); afterwards, outside
           the headline's timed region, the same run times configs[2] (10M x
-          300 bp + adapters, 25 % of the reads carrying a spliced adapter) and
-          configs[4] (ragged 1-20 kb) for a few steps each -> "also".
+          300 bp + adapters, 25 % of the reads carrying a spliced adapter),
+          configs[4] (ragged 1-20 kb) and trimmed 150 bp reads for a few steps
+          each -> "also", and the two other tiers of SURVEY 8d -> "tiers":
+          H2D-inclusive (pinned double buffer) and the end-to-end CLI on a
+          .fq.gz made on the spot.  Neither is ever `value`.
   N > 1   configs[3]'s per-GPU share: paired 2 x 50M x 150 bp over 8 GPUs =
           2 x 6.25M reads per GPU, two independent accumulators (forward /
           reverse mate, quack.c:911-921); weak scaling — every rank holds its
           own share, there is no data-path collective, and the job ends with
           ONE RCCL all-reduce of each mate's integer table, inside the timed
-          region.
+          region.  "n1_reference" = the same per-GPU workload on rank 0 alone,
+          measured before the process group forms (like-for-like one-GPU
+          figure); "also.cfg3_share" = configs[2] cut into N shares (300 bp +
+          adapters), with its own n1_reference.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     dominant kernel, algorithmic bytes (2 B/base [+8 B/read ragged,
-               +12 gapped]) / average launch duration from HIP events on the
-               launch stream; `batch_ms` = all kernels of a step
+               +12 gapped, +4 strided]) / average launch duration from HIP
+               events on the launch stream (every launch up to 50 steps);
+               kernel_ms_min / _max; `batch_ms` = all kernels of a step
   cpu_baseline the oracle (CPU restatement, kind "port") on one host core over
                the same bytes; cpu_baseline_threads = the same on every host
                core the process may use — reported baselines, not the target
@@ -43,7 +50,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0   # the guide's measured copy ceiling
-TIMING_EVERY = 8
+TIMED_LAUNCHES_MAX = 50   # HIP events around every launch up to 50 steps, around every ceil(K/50)th beyond
 METRIC = "bases/sec on synthetic 150 bp FASTQ; achieved HBM GB/s vs peak"
 TRAFFIC_SOURCE = "profiles/hbm_traffic.json (rocprofv3 --pmc passes, builder-run; not measured in this run)"
 
@@ -80,7 +87,9 @@ def parse_args():
     ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS),
                     help="auto: cfg2 at N=1 (the headline), cfg4's per-GPU share at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="N=1: skip the cfg3 / cfg5 lines")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra workloads (N=1: cfg3 / cfg5 / trimmed; N>1: cfg3's share)")
+    ap.add_argument("--no-tiers", action="store_true", help="N=1: skip the H2D-inclusive and end-to-end CLI tiers (SURVEY 8d)")
+    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end tier's .fq.gz (x 150 bp)")
     ap.add_argument("--also-steps", type=int, default=50)
     # rehearsal on a one-GPU box: several ranks share one device and the table
     # exchange goes through gloo (the driver's runs use the defaults: nccl = RCCL)
@@ -294,11 +303,40 @@ def cpu_baselines(np, b, w, ads, threads=True, budget=3_000_000_000):
     return one, many
 
 
-def time_workload(torch, quack_amd, w, b, local, bits, steps, warmup, stream=None):
-    """W + K device-resident passes of one workload on a fresh accumulator -> (roofline dict, table sums)"""
-    acc = quack_amd.Accumulator(local, bits, max_len_hint=b["max_len"])
+def timing_every(steps):
+    """events around every launch when steps <= 50 (a pair of event records costs ~10 us of stream time),
+    around every ceil(steps/50)th launch beyond that"""
+    return max(1, -(-steps // TIMED_LAUNCHES_MAX))
 
-    def step():
+
+def roofline_of(alg_bytes, kernel_ms, batch_ms, launches, traffic, kmin=None, kmax=None):
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    whole = alg_bytes / (batch_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic else None,
+            "kernel": "qk::hist_kernel", "kernel_ms": kernel_ms, "kernel_ms_min": kmin, "kernel_ms_max": kmax,
+            "batch_ms": batch_ms, "frac_whole_batch": whole / HBM_PEAK_GBS,
+            # (SURVEY 8d: "also quote vs the 6.29 TB/s measured-copy ceiling" of MI355X_MICROARCH.md)
+            "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
+            "batch_kernels": "every kernel of a step on the launch stream (reach pre-pass, length kernel, hist_kernel, adapter count)",
+            "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches}
+
+
+class Job:
+    """one workload resident in this rank's HBM: the batch (two for a pair) and how a step submits it"""
+
+    def __init__(self, ctx, name, w, seed, seed_mate):
+        torch, np = ctx["torch"], ctx["np"]
+        self.ctx, self.name, self.w = ctx, name, w
+        self.bits, self.ads = synthetic_adapter_bits(np) if w["adapters"] else (None, None)
+        self.b = make_batch(torch, np, w, seed=seed, device=ctx["device"], quality=ctx["args"].quality, ads=self.ads)
+        self.b2 = None
+        if w.get("paired"):   # the reverse mate: its own batch (qualities skewed lower, SURVEY 8d) and its own accumulator
+            self.b2 = make_batch(torch, np, w, seed=seed_mate, device=ctx["device"], quality=ctx["args"].quality, q_hi_override=30)
+        self.mates = 2 if self.b2 is not None else 1
+        self.alg_bytes = alg_bytes_of(self.b)
+
+    def submit(self, acc, b, stream):
         if b.get("stride"):
             acc.submit_device_strided(b["seq"], b["qual"], b["d_len"], b["n"], b["stride"], b["max_len"], stream=stream)
         elif b["d_len"] is not None:
@@ -307,37 +345,193 @@ def time_workload(torch, quack_amd, w, b, local, bits, steps, warmup, stream=Non
         else:
             acc.submit_device(b["seq"], b["qual"], b["d_off"], b["n"], b["total"], b["max_len"], stream=stream)
 
-    for _ in range(warmup):
-        step()
-    acc.sync()
-    torch.cuda.synchronize()
-    acc.timing(min(TIMING_EVERY, max(1, steps // 5)))   # (at least five timed launches)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    acc.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    hist_ms, batch_ms, launches = acc.timing_read_batch()
-    sd = acc.finish()
-    acc.close()
-    got = int(sd.bases[:, 91:95].sum())
-    if got != (warmup + steps) * b["total"]:
-        raise SystemExit("counter check failed (%s): content sum %d != %d" % (w["label"], got, (warmup + steps) * b["total"]))
-    return elapsed, hist_ms / max(launches, 1), batch_ms / max(launches, 1), launches, sd
+    def run(self, steps, warmup, world=1, exchange=False):
+        """W warm-up + exactly K timed passes on fresh accumulators, barrier + synchronize on both sides, with the
+        path's single exchange (all-reduce of every mate's table) inside the timed region when `exchange`.
+        -> dict(elapsed = max over ranks, my_elapsed, kernel/batch ms per launch, launches, min/max)"""
+        ctx = self.ctx
+        torch, quack_amd, qd, dist = ctx["torch"], ctx["quack_amd"], ctx["qd"], ctx["dist"]
+        local, device, args = ctx["local"], ctx["device"], ctx["args"]
+        b, b2 = self.b, self.b2
+        acc = quack_amd.Accumulator(local, self.bits, max_len_hint=b["max_len"])
+        mate = quack_amd.Accumulator(local, self.bits, max_len_hint=b["max_len"]) if b2 is not None else None
+        # paired: both mates on ONE stream, so that every launch has the GPU to itself and its
+        # HIP-event duration means something (on separate streams the two kernels would overlap)
+        side = torch.cuda.Stream(device) if mate is not None else None   # (the default stream's handle is NULL)
+        stream = side.cuda_stream if side is not None else None
+        via_host = args.backend == "gloo"
+
+        def step():
+            self.submit(acc, b, stream)
+            if mate is not None:
+                self.submit(mate, b2, stream)
+
+        def fence():
+            acc.sync()
+            if mate is not None:
+                mate.sync()
+            torch.cuda.synchronize()
+            if exchange:
+                dist.barrier()
+
+        for _ in range(warmup):
+            step()
+        if exchange:
+            # warm the exchange too (communicator, collective kernels) — on a throwaway
+            # accumulator, so that the measured tables stay the sum of exactly W+K steps
+            with quack_amd.Accumulator(local, None, max_len_hint=b["max_len"]) as tmp:
+                qd.allreduce_accumulator(tmp, via_host=via_host)
+        fence()
+        every = timing_every(steps)
+        acc.timing(every)
+        if mate is not None:
+            mate.timing(every)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if exchange:
+            qd.allreduce_accumulator(acc, via_host=via_host)   # the path's single exchange (RCCL over xGMI)
+            if mate is not None:
+                qd.allreduce_accumulator(mate, via_host=via_host)
+        fence()
+        my_elapsed = elapsed = time.perf_counter() - t0
+        kernel_ms, batch_ms, launches = acc.timing_read_batch()
+        kmin, kmax = acc.timing_read_range()
+        if mate is not None:
+            ms2, bms2, l2 = mate.timing_read_batch()
+            lo2, hi2 = mate.timing_read_range()
+            kernel_ms, batch_ms, launches = kernel_ms + ms2, batch_ms + bms2, launches + l2
+            kmin, kmax = min(kmin, lo2), max(kmax, hi2)
+        if exchange:
+            cd = device if args.backend == "nccl" else "cpu"
+            t = torch.tensor([elapsed], dtype=torch.float64, device=cd)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # sanity: the counters must add up (every base carries one score and one content bin); after the
+        # all-reduce every rank holds the sum over ranks (every rank's batch has the same number of bases
+        # for fixed-length workloads)
+        ranks = world if exchange else 1
+        sd = acc.finish()
+        got = int(sd.bases[:, 91:95].sum())
+        fixed = b["d_off"] is None and not b.get("stride")
+        if fixed or ranks == 1:
+            if got != (warmup + steps) * b["total"] * ranks:
+                raise SystemExit("counter check failed (%s): content sum %d != %d" % (self.w["label"], got, (warmup + steps) * b["total"] * ranks))
+        if fixed and sd.number_of_sequences != (warmup + steps) * b["n"] * ranks:
+            raise SystemExit("counter check failed (%s): %d sequences" % (self.w["label"], sd.number_of_sequences))
+        acc.close()
+        if mate is not None:
+            sd2 = mate.finish()
+            if int(sd2.bases[:, 91:95].sum()) != (warmup + steps) * b2["total"] * ranks:
+                raise SystemExit("counter check failed for the reverse mate")
+            mate.close()
+        L = max(launches, 1)
+        return {"elapsed": elapsed, "my_elapsed": my_elapsed, "kernel_ms": kernel_ms / L, "batch_ms": batch_ms / L,
+                "launches": launches, "kernel_ms_min": kmin, "kernel_ms_max": kmax, "steps": steps, "warmup": warmup}
+
+    def line(self, r, world, traffic):
+        """the parts of a JSON entry every workload shares"""
+        bases = world * r["steps"] * self.b["total"] * self.mates
+        return {"workload": self.w["label"], "steps": r["steps"], "warmup": r["warmup"], "value": bases / r["elapsed"], "unit": "bases/s",
+                "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
+                "roofline": roofline_of(self.alg_bytes, r["kernel_ms"], r["batch_ms"], r["launches"], traffic,
+                                        r["kernel_ms_min"], r["kernel_ms_max"])}
 
 
-def roofline_of(alg_bytes, kernel_ms, batch_ms, launches, traffic):
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    whole = alg_bytes / (batch_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic else None,
-            "kernel": "qk::hist_kernel", "kernel_ms": kernel_ms,
-            "batch_ms": batch_ms, "frac_whole_batch": whole / HBM_PEAK_GBS,
-            # ("also quote vs the 6.29 TB/s measured-copy ceiling" of MI355X_MICROARCH.md)
-            "frac_of_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
-            "batch_kernels": "every kernel of a step on the launch stream (reach pre-pass, first-hit reset, hist_kernel, adapter count)",
-            "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches}
+def gather_ranks(ctx, r):
+    """per-rank kernel time, step time and device of a run (all_gather over the group)"""
+    torch, dist, args = ctx["torch"], ctx["dist"], ctx["args"]
+    cd = ctx["device"] if args.backend == "nccl" else "cpu"
+    mine = torch.tensor([r["kernel_ms"], r["my_elapsed"] / r["steps"] * 1e3, float(ctx["local"])], dtype=torch.float64, device=cd)
+    allr = [torch.zeros_like(mine) for _ in range(ctx["world"])]
+    dist.all_gather(allr, mine)
+    return [{"rank": i, "device": int(x[2].item()), "kernel_ms": round(float(x[0].item()), 4),
+             "ms_per_step": round(float(x[1].item()), 4)} for i, x in enumerate(allr)]
+
+
+# --------------------------------------------------------------------------
+# SURVEY 8d asks for three tiers; `value` is (i), kernels over batches resident in HBM.  The other two:
+def tier_h2d(ctx, n_batches=48):
+    """(ii) H2D-inclusive: pre-parsed host batches in the accumulator's two pinned slots, qk_accum_acquire /
+    qk_accum_commit in a loop — hipMemcpyAsync of batch k+1 under the kernels of batch k, as the C host feed
+    drives it (pipeline.c); bound by PCIe Gen5 x16 (~63 GB/s -> ~31 Gbases/s)"""
+    np, quack_amd = ctx["np"], ctx["quack_amd"]
+    L = 150
+    rng = np.random.default_rng(11)
+    with quack_amd.Accumulator(ctx["local"], None, max_len_hint=L) as acc:
+        n = 0
+        for _ in range(2):   # both slots: allocate (page-lock) and fill them once; their contents stay
+            s, q, _ = acc.acquire()
+            n = len(s) // L
+            s[:n * L] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * L, dtype=np.uint8)]
+            q[:n * L] = rng.integers(35, 75, n * L, dtype=np.uint8)
+            acc.commit(n, n * L, L)
+        acc.sync()
+        t0 = time.perf_counter()
+        for _ in range(n_batches):
+            acc.acquire()
+            acc.commit(n, n * L, L)
+        acc.sync()
+        dt = time.perf_counter() - t0
+        sd = acc.finish()
+    if int(sd.bases[:, 91:95].sum()) != (n_batches + 2) * n * L:
+        raise SystemExit("counter check failed (H2D tier)")
+    return {"value": n_batches * n * L / dt, "unit": "bases/s", "pcie_GBps": 2.0 * n_batches * n * L / dt / 1e9,
+            "batches": n_batches, "reads_per_batch": n, "slot_MiB_per_array": round(len(s) / 2**20, 1),
+            "what": "pinned double buffer -> hipMemcpyAsync -> kernels (qk_accum_acquire/commit), 150 bp fixed-length batches"}
+
+
+def tier_end_to_end(ctx, n_reads):
+    """(iii) end-to-end CLI: `quack -u reads.fq.gz > svg` on a gzip file made here (tools/gen_fastq pieces, concatenated
+    members, level 6), wall clock of the whole process; the oracle CLI on the same file as the CPU figure"""
+    import shutil
+    import tempfile
+    gen, quack = os.path.join(ROOT, "tools", "gen_fastq"), os.path.join(ROOT, "quack_amd", "host", "quack")
+    oracle = os.path.join(ROOT, "oracle", "_build", "quack_oracle")
+    if not (os.path.exists(gen) and os.path.exists(quack)):
+        return {"skipped": "tools/gen_fastq or quack_amd/host/quack not built"}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    pieces = max(1, min(16, cores, n_reads // 50_000))
+    d = tempfile.mkdtemp(prefix="quack_e2e_")
+    try:
+        t0 = time.perf_counter()
+        per = n_reads // pieces
+        procs = [subprocess.Popen([gen, os.path.join(d, "p%d.fq.gz" % i), str(per), "150", "150", str(2000 + i)]) for i in range(pieces)]
+        if any(p.wait() != 0 for p in procs):
+            return {"skipped": "gen_fastq failed"}
+        path = os.path.join(d, "e2e.fq.gz")
+        with open(path, "wb") as out:
+            for i in range(pieces):
+                with open(os.path.join(d, "p%d.fq.gz" % i), "rb") as f:
+                    shutil.copyfileobj(f, out, 1 << 24)
+                os.unlink(os.path.join(d, "p%d.fq.gz" % i))
+        t_gen = time.perf_counter() - t0
+        bases = per * pieces * 150
+        env = dict(os.environ)
+        env.pop("QUACK_DEVICES", None)
+        walls, svg_len = [], 0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = subprocess.run([quack, "-u", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            walls.append(time.perf_counter() - t0)
+            if r.returncode != 0 or not r.stdout.startswith(b"<svg"):
+                return {"skipped": "quack failed: %s" % r.stderr[-200:].decode(errors="replace")}
+            svg_len = len(r.stdout)
+        out = {"value": bases / min(walls), "unit": "bases/s", "wall_s": [round(x, 3) for x in walls], "best_wall_s": round(min(walls), 3),
+               "reads": per * pieces, "bases": bases, "file_bytes": os.path.getsize(path), "svg_bytes": svg_len,
+               "file": "%d gzip members (level 6) of %d reads x 150 bp, made in %.1f s by %d gen_fastq processes" % (pieces, per, t_gen, pieces),
+               "decoder_threads": os.environ.get("QUACK_THREADS", "default: host cores / GPUs of the node, at most 32"),
+               "what": "quack -u file.fq.gz > svg: process start to exit (inflate + tokenize on host threads, pinned double buffer, kernels, transform, draw)"}
+        if os.path.exists(oracle) and not ctx["args"].no_cpu_baseline:
+            t0 = time.perf_counter()
+            r = subprocess.run([oracle, "time", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            w_or = time.perf_counter() - t0
+            if r.returncode == 0:
+                out["cpu_baseline"] = {"value": bases / w_or, "unit": "bases/s", "cores": 1, "kind": "port", "wall_s": round(w_or, 3),
+                                       "sample": "the same file, whole (oracle/oracle_cli.c: zlib gzread + the restated loop, no drawing)"}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -365,13 +559,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.device is not None:
         local = args.device
+    if args.backend == "nccl" and world > 1 and local >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants device %d, the node shows %d (RCCL needs one GPU per rank; --backend gloo --device 0 rehearses on one)"
+                         % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group("gloo")
+    ctx = dict(torch=torch, np=np, dist=dist, quack_amd=quack_amd, qd=qd, args=args, rank=rank, local=local, world=world, device=device)
 
     name = args.workload if args.workload != "auto" else ("cfg2" if world == 1 else "cfg4")
     w = dict(WORKLOADS[name])
@@ -380,147 +573,106 @@ def main():
     if args.read_len and not w["ragged"]:
         w["L"] = args.read_len
         w["label"] += " [read length overridden: %d]" % args.read_len
-    bits, ads = synthetic_adapter_bits(np) if w["adapters"] else (None, None)
-    b = make_batch(torch, np, w, seed=2 + rank, device=device, quality=args.quality, ads=ads)
-    seq, qual, d_off, d_len = b["seq"], b["qual"], b["d_off"], b["d_len"]
-    total, max_len, extent, n = b["total"], b["max_len"], b["extent"], b["n"]
-    alg_bytes = alg_bytes_of(b)
+    job = Job(ctx, name, w, seed=2 + rank, seed_mate=1000 + rank)
 
-    acc = quack_amd.Accumulator(local, bits, max_len_hint=max_len)
-    mate = None
-    if w.get("paired"):
-        # the reverse mate: its own batch and its own accumulator
-        b2 = make_batch(torch, np, w, seed=1000 + rank, device=device, quality=args.quality, q_hi_override=30)
-        seq2, qual2 = b2["seq"], b2["qual"]
-        mate = quack_amd.Accumulator(local, bits, max_len_hint=max_len)
-
-    # paired: both mates on ONE stream, so that every launch has the GPU to itself and its
-    # HIP-event duration means something (on separate streams the two kernels would overlap)
-    side = torch.cuda.Stream(device) if mate is not None else None   # (the default stream's handle is NULL)
-    shared_stream = side.cuda_stream if side is not None else None
-
-    def step():
-        if b.get("stride"):
-            acc.submit_device_strided(seq, qual, d_len, n, b["stride"], max_len, stream=shared_stream)
-        elif d_len is not None:
-            acc.submit_device_gapped(seq, qual, d_off, d_len, n, extent, max_len, aligned=True, stream=shared_stream)
+    # N > 1: the SAME per-GPU workload on rank 0 alone, before the group forms (the other ranks are waiting in the
+    # rendezvous, their GPUs idle) — the like-for-like one-GPU figure for the scaling efficiency.  (N = 1 runs config 2:
+    # 10M reads into one accumulator; N > 1 runs config 4's share: 2 x 6.25M into two — 4-5 % apart on one GPU.)
+    n1_ref = None
+    if world > 1 and rank == 0:
+        n1_ref = job.run(args.steps, args.warmup, world=1, exchange=False)
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
         else:
-            acc.submit_device(seq, qual, d_off, n, total, max_len, stream=shared_stream)
-        if mate is not None:
-            mate.submit_device(seq2, qual2, None, n, total, max_len, stream=shared_stream)
+            dist.init_process_group("gloo")
 
-    def fence():
-        acc.sync()
-        if mate is not None:
-            mate.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+    res = job.run(args.steps, args.warmup, world=world, exchange=world > 1)
+    per_rank = gather_ranks(ctx, res) if world > 1 else None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    traffic_tab = json.load(open(tf)) if os.path.exists(tf) else {}
+    head = job.line(res, world, traffic_tab.get(name))
+    n1_line = job.line(n1_ref, 1, traffic_tab.get(name)) if n1_ref is not None else None
+    mates, n, total, max_len = job.mates, job.b["n"], job.b["total"], job.b["max_len"]
 
-    via_host = args.backend == "gloo"
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        # warm the exchange too (communicator, collective kernels) — on a throwaway
-        # accumulator, so that the measured tables stay the sum of exactly W+K steps
-        with quack_amd.Accumulator(local, None, max_len_hint=max_len) as tmp:
-            qd.allreduce_accumulator(tmp, via_host=via_host)
-    fence()
-    # HIP events around every 8th batch: the events themselves take ~10 us of stream time per batch (2 % of a
-    # config-2 step), and `value` is this loop's wall clock
-    acc.timing(TIMING_EVERY)
-    if mate is not None:
-        mate.timing(TIMING_EVERY)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if world > 1:
-        qd.allreduce_accumulator(acc, via_host=via_host)   # the path's single exchange (RCCL over xGMI)
-        if mate is not None:
-            qd.allreduce_accumulator(mate, via_host=via_host)
-    fence()
-    elapsed = time.perf_counter() - t0
-    my_elapsed = elapsed
-    kernel_ms, batch_ms, launches = acc.timing_read_batch()
-    mates = 2 if mate is not None else 1
-    if mate is not None:
-        ms2, bms2, l2 = mate.timing_read_batch()
-        kernel_ms, batch_ms, launches = kernel_ms + ms2, batch_ms + bms2, launches + l2
-    per_rank = None
-    if world > 1:
-        cd = device if args.backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cd)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        mine = torch.tensor([kernel_ms / max(launches, 1), my_elapsed / args.steps * 1e3, float(local)],
-                            dtype=torch.float64, device=cd)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = [{"rank": i, "device": int(x[2].item()), "kernel_ms": round(float(x[0].item()), 4),
-                     "ms_per_step": round(float(x[1].item()), 4)} for i, x in enumerate(allr)]
-
-    # sanity: the counters must add up (every base carries one score and one content bin)
-    sd = acc.finish()
-    # after the all-reduce every rank holds the sum over ranks (equal batch sizes for fixed-length workloads)
-    got = int(sd.bases[:, 91:95].sum())
-    if d_off is None and not b.get("stride"):
-        expect = (args.warmup + args.steps) * total * world
-        if got != expect:
-            raise SystemExit("counter check failed: content sum %d != %d" % (got, expect))
-        if sd.number_of_sequences != (args.warmup + args.steps) * n * world:
-            raise SystemExit("counter check failed: %d sequences" % sd.number_of_sequences)
-    elif world == 1 and got != (args.warmup + args.steps) * total:
-        raise SystemExit("counter check failed: content sum %d" % got)
-    acc.close()
-    if mate is not None:
-        sd2 = mate.finish()
-        if int(sd2.bases[:, 91:95].sum()) != (args.warmup + args.steps) * total * world:
-            raise SystemExit("counter check failed for the reverse mate")
-        mate.close()
-
+    out = None
     if rank == 0:
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        traffic_tab = json.load(open(tf)) if os.path.exists(tf) else {}
-        kms, bms = kernel_ms / max(launches, 1), batch_ms / max(launches, 1)
         out = {
             "metric": METRIC,
-            "value": world * args.steps * total * mates / elapsed,
-            "unit": "bases/s",
+            "value": head["value"], "unit": "bases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": w["label"] + ("" if args.quality == "uniform" else " [quality: %s]" % args.quality),
                        "reads_per_gpu": n * mates, "bases_per_gpu_per_step": total * mates,
                        "resident": "HBM", "parallelism": "batch-sharded x%d, one all-reduce of u64 tables%s" % (
-                           world, " per mate" if mate is not None else "")},
-            "roofline": roofline_of(alg_bytes, kms, bms, launches, traffic_tab.get(name)),
+                           world, " per mate" if mates == 2 else "")},
+            "roofline": head["roofline"],
         }
         if world > 1:
+            import socket as _socket
+            try:
+                rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:   # (a torch build without the binding: the line still goes out)
+                rccl = None
             out["ranks"] = {"world_size": dist.get_world_size(), "backend": "rccl" if args.backend == "nccl" else "gloo (rehearsal)",
+                            "rccl_version": rccl, "host": _socket.gethostname(), "devices_visible": torch.cuda.device_count(),
+                            "device_name": torch.cuda.get_device_name(local),
                             "exchange": "%d x all-reduce(SUM, u64) of %d words, inside the timed region" % (
                                 mates, 97 * ((max_len + 63) // 64 * 64) + 1),
                             "per_rank": per_rank}
-        if world == 1 and args.workload == "auto" and not args.no_also:
+            # like for like: efficiency(N) = value / (N * n1_reference.value)
+            out["n1_reference"] = dict(n1_line, what="the same per-GPU workload (both mates, no exchange) on rank 0 alone, "
+                                       "before the process group formed; scaling efficiency = value / (n_gpus * this value)")
+            out["efficiency_vs_n1_reference"] = head["value"] / (world * n1_line["value"])
+
+    # N > 1: config 3's share as well — 10M x 300 bp + adapters cut into N shares (north_star asks for 150 bp AND
+    # 300 bp at 1/2/4/8 GPUs); again with the one-GPU figure of the same share measured on rank 0 alone
+    if world > 1 and args.workload == "auto" and not args.no_also:
+        del job
+        torch.cuda.empty_cache()
+        w3 = dict(WORKLOADS["cfg3"])
+        w3["n"] = w3["n"] // world
+        w3["label"] = "config 3's share: 10M-read 300 bp + adapters (25%% of the reads spliced) over %d GPUs = %d reads per GPU" % (world, w3["n"])
+        job3 = Job(ctx, "cfg3", w3, seed=3 + rank, seed_mate=0)
+        alone = job3.run(args.also_steps, 15, world=1, exchange=False) if rank == 0 else None
+        dist.barrier()
+        r3 = job3.run(args.also_steps, 15, world=world, exchange=True)
+        ranks3 = gather_ranks(ctx, r3)
+        if rank == 0:
+            e = job3.line(r3, world, None)
+            e["reads_with_spliced_adapter_rank0"] = job3.b["spliced"]
+            e["per_rank"] = ranks3
+            e["n1_reference"] = job3.line(alone, 1, None)
+            e["efficiency_vs_n1_reference"] = e["value"] / (world * e["n1_reference"]["value"])
+            out["also"] = {"cfg3_share": e}
+        del job3
+        torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1:
+        if args.workload == "auto" and not args.no_also:
             also = {}
             for nm in ("cfg3", "cfg5", "trimmed"):
-                w2 = dict(WORKLOADS[nm])
-                bits2, ads2 = synthetic_adapter_bits(np) if w2["adapters"] else (None, None)
-                bb = make_batch(torch, np, w2, seed={"cfg3": 3, "cfg5": 6, "trimmed": 7}[nm], device=device, ads=ads2)
-                el, kms2, bms2, l2, _ = time_workload(torch, quack_amd, w2, bb, local, bits2, args.also_steps, 15)
-                entry = {"workload": w2["label"], "steps": args.also_steps, "value": args.also_steps * bb["total"] / el,
-                         "unit": "bases/s", "ms_per_step": el / args.also_steps * 1e3,
-                         "roofline": roofline_of(alg_bytes_of(bb), kms2, bms2, l2, traffic_tab.get(nm))}
+                j2 = Job(ctx, nm, dict(WORKLOADS[nm]), seed={"cfg3": 3, "cfg5": 6, "trimmed": 7}[nm], seed_mate=0)
+                entry = j2.line(j2.run(args.also_steps, 15), 1, traffic_tab.get(nm))
                 if nm == "cfg3":
-                    entry["reads_with_spliced_adapter"] = bb["spliced"]
+                    entry["reads_with_spliced_adapter"] = j2.b["spliced"]
                 if not args.no_cpu_baseline:
-                    entry["cpu_baseline"], _ = cpu_baselines(np, bb, w2, ads2, threads=False, budget=1_500_000_000)
+                    entry["cpu_baseline"], _ = cpu_baselines(np, j2.b, j2.w, j2.ads, threads=False, budget=1_500_000_000)
                 also[nm] = entry
-                del bb
+                del j2
                 torch.cuda.empty_cache()
             out["also"] = also
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baselines(np, b, w, ads)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baselines(np, job.b, w, job.ads)
+        if args.workload == "auto" and not args.no_tiers:
+            # "report all three" — (i) is `value`; neither of these is ever `value`
+            del job
+            torch.cuda.empty_cache()
+            out["tiers"] = {"kernel_only": {"value": out["value"], "unit": "bases/s", "what": "this line's value: batches resident in HBM"},
+                            "h2d_inclusive": tier_h2d(ctx), "end_to_end": tier_end_to_end(ctx, args.e2e_reads)}
+    if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.barrier()

@@ -196,6 +196,8 @@ int qk_accum_timing_read(qk_accum *acc, double *total_ms, uint64_t *launches);
  * kernel, first-hit reset, histogram, adapter count): hist_ms <= batch_ms. */
 int qk_accum_timing_read_batch(qk_accum *acc, double *hist_ms, double *batch_ms,
                                uint64_t *launches);
+/* Shortest and longest histogram-kernel launch among those (ms); both 0 when none was timed. */
+int qk_accum_timing_read_range(qk_accum *acc, double *hist_min_ms, double *hist_max_ms);
 
 /* ---- tuning knobs (env: QUACK_HIP_THREADS / _UNROLL / _TILE) ---------- */
 int qk_accum_configure(qk_accum *acc, int threads_per_wg, int unroll,

@@ -42,5 +42,14 @@ if [ -x "$ROOT/tools/gen_fastq" ]; then
   sha256sum "$TMP/config1.fq.gz" | cut -d' ' -f1 > "$G/svg/config1.input.sha256"
   gzip -n -9 -f "$G/svg/config1.svg"
   echo "golden config1 $(stat -c %s "$G/svg/config1.svg.gz") bytes"
+  # BASELINE.json configs[3]'s shape, CPU-runnable: paired, 100k reads per mate, 150 bp, R2 qualities skewed
+  # lower (Q in [2,30]), seeds 4 / 5 — two independent accumulations and the mirrored second panel
+  # (quack.c:879,911-921).  Inputs regenerated bit-identically by tools/gen_fastq wherever the test runs.
+  "$ROOT/tools/gen_fastq" "$TMP/config4_R1.fq.gz" 100000 150 150 4
+  "$ROOT/tools/gen_fastq" "$TMP/config4_R2.fq.gz" 100000 150 150 5 2 30
+  (cd "$TMP" && "$REF" -1 config4_R1.fq.gz -2 config4_R2.fq.gz > "$G/svg/config4.svg" 2> "$G/svg/config4.err"; echo $? > "$G/svg/config4.rc")
+  (cd "$TMP" && sha256sum config4_R1.fq.gz config4_R2.fq.gz) > "$G/svg/config4.input.sha256"
+  gzip -n -9 -f "$G/svg/config4.svg"
+  echo "golden config4 $(stat -c %s "$G/svg/config4.svg.gz") bytes"
   rm -rf "$TMP"
 fi

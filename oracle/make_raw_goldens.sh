@@ -37,4 +37,8 @@ if [ -x "$ROOT/tools/gen_fastq" ]; then
   "$ROOT/tools/gen_fastq" "$TMP/config1.fq.gz" 100000 150 150 12345
   [ "$(sha256sum "$TMP/config1.fq.gz" | cut -d' ' -f1)" = "$(cat "$G/svg/config1.input.sha256")" ]
   run config1 "$TMP" -u config1.fq.gz
+  "$ROOT/tools/gen_fastq" "$TMP/config4_R1.fq.gz" 100000 150 150 4
+  "$ROOT/tools/gen_fastq" "$TMP/config4_R2.fq.gz" 100000 150 150 5 2 30
+  (cd "$TMP" && sha256sum config4_R1.fq.gz config4_R2.fq.gz) | cmp - "$G/svg/config4.input.sha256"
+  run config4 "$TMP" -1 config4_R1.fq.gz -2 config4_R2.fq.gz
 fi

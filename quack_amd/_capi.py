@@ -82,6 +82,7 @@ def hip():
     L.qk_accum_timing_enable.argtypes = [c_vp, ctypes.c_int]
     L.qk_accum_timing_read.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double), c_u64p]
     L.qk_accum_timing_read_batch.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_u64p]
+    L.qk_accum_timing_read_range.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.qk_accum_configure.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     _hip = L
     return L

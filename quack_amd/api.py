@@ -254,6 +254,28 @@ class Accumulator:
         _check(self._L.qk_accum_timing_read_batch(self._h, ctypes.byref(ms), ctypes.byref(bms), ctypes.byref(n)))
         return ms.value, bms.value, n.value
 
+    def timing_read_range(self):
+        """(shortest, longest) timed histogram-kernel launch in ms"""
+        lo, hi = ctypes.c_double(), ctypes.c_double()
+        _check(self._L.qk_accum_timing_read_range(self._h, ctypes.byref(lo), ctypes.byref(hi)))
+        return lo.value, hi.value
+
+    # -- the pinned double buffer itself (qk_accum_acquire / qk_accum_commit): what the C host feed drives
+    def acquire(self):
+        """-> (seq, qual, offsets) numpy views of the next pinned batch slot (capacity: len(seq) bytes,
+        len(offsets) - 1 reads); valid until commit()"""
+        hs, hq = ctypes.POINTER(ctypes.c_uint8)(), ctypes.POINTER(ctypes.c_uint8)()
+        ho = ctypes.POINTER(ctypes.c_uint64)()
+        capb, capr = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(self._L.qk_accum_acquire(self._h, ctypes.byref(hs), ctypes.byref(hq), ctypes.byref(ho),
+                                        ctypes.byref(capb), ctypes.byref(capr)))
+        return (np.ctypeslib.as_array(hs, shape=(capb.value,)), np.ctypeslib.as_array(hq, shape=(capb.value,)),
+                np.ctypeslib.as_array(ho, shape=(capr.value + 1,)))
+
+    def commit(self, n_reads, total_bytes, read_len=0):
+        """enqueue H2D + kernels of the acquired slot; read_len > 0: fixed-length batch (offsets unused)"""
+        _check(self._L.qk_accum_commit(self._h, n_reads, total_bytes, 0 if read_len else 1, read_len))
+
     def finish(self):
         a, b = ctypes.c_uint64(), ctypes.c_uint64()
         _check(self._L.qk_accum_finish(self._h, None, 0, ctypes.byref(a), ctypes.byref(b)))

@@ -56,6 +56,9 @@ constexpr int kRowContent = 91;
 constexpr int kRowLength = 95;
 constexpr int kRowKmer = 96;
 constexpr uint32_t kMaxReadsPerSlice = 65535; // u16 counters: <=1 hit/read/pos
+// bits of the device status word (HistParams::status), read back by qk_accum_sync
+constexpr uint32_t kStatusNotAligned = 1u;   // a batch submitted as QK_BATCH_ALIGNED128 holds a read off a 128-byte line
+constexpr uint32_t kStatusBadLength = 2u;    // a device-side lengths[] entry exceeds the stride / the table
 
 // Device-side parameter block of one launch.
 struct HistParams {
@@ -72,8 +75,10 @@ struct HistParams {
   const uint32_t *reach;
   uint32_t stage_reads;         // ragged: reads staged per pass (a multiple of 1024: short reads want long passes)
   uint32_t lengths_done;        // length_count / the kmers==NULL count were taken by ragged_length_kernel
-  uint32_t *status;             // bit 0 is set when a batch submitted as 128-byte aligned is not
+  uint32_t *status;             // kStatus* bits: what a kernel found wrong with the batch (fails the next sync)
   uint32_t check_aligned;       // the batch was submitted as QK_BATCH_ALIGNED128 (whichever variant runs it)
+  uint32_t len_limit;           // strided batches: the longest read the caller declared (lengths[] on the device are
+                                //   checked against it by the length kernels; 0: nothing to check)
   unsigned long long *table;    // planar [kOutRows][table_len]
   uint32_t *first_hit;          // per-read first adapter hit (ADAPT only)
   const uint32_t *kmer_bits;    // 2^20-bit exact table (ADAPT only)
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
               o0 = obase[id];
               len = lbase ? lbase[id] : (uint32_t)(obase[id + 1] - o0);
             }
-            if ((AL || p.check_aligned) && (o0 & 127u) != 0) atomicOr(p.status, 1u);   // the producer's promise does not hold
+            if ((AL || p.check_aligned) && (o0 & 127u) != 0) atomicOr(p.status, kStatusNotAligned);   // the producer's promise does not hold
           }
           if (!p.lengths_done) {   // wave-uniform
             // length_count (quack.c:219) of the reads that END in this tile — every read is staged
@@ -1240,7 +1245,10 @@ __global__ __launch_bounds__(kLenThreads) void ragged_length_kernel(const HistPa
     mine += (in && len > 10u) ? 1u : 0u;
     const uint32_t lp = len - 1u;
     wave_count_lds(cnt, lp, in && len != 0 && lp < kLenLds);
-    wave_count_global(&p.table[(uint64_t)kRowLength * p.table_len], lp, in && len != 0 && lp >= kLenLds);
+    // (a length beyond the table can only come from device-side lengths[] the host never saw: it is
+    // reported through the status word — the next sync fails — and never written)
+    if (in && len != 0 && (lp >= p.table_len || (p.len_limit && len > p.len_limit))) atomicOr(p.status, kStatusBadLength);
+    wave_count_global(&p.table[(uint64_t)kRowLength * p.table_len], lp, in && len != 0 && lp >= kLenLds && lp < p.table_len);
   };
   // (whole waves per round: wave_count_lds uses ballots)
   if (p.lengths && (reinterpret_cast<uintptr_t>(p.lengths) & 15u) == 0) {
@@ -1296,7 +1304,9 @@ __global__ __launch_bounds__(kLenThreads) void short_length_kernel(const HistPar
   uint32_t mine = 0;
   auto one = [&](uint32_t len) {
     mine += len > 10u ? 1u : 0u;
-    if (len != 0 && len <= kShortLen) atomicAdd(&cnt[(len - 1u) * 32u + col], 1u);
+    // strided batches: no read is longer than the caller declared (<= the stride; the table holds that many positions)
+    if (len > p.len_limit || len > p.table_len) atomicOr(p.status, kStatusBadLength);
+    else if (len != 0 && len <= kShortLen) atomicAdd(&cnt[(len - 1u) * 32u + col], 1u);
     else if (len != 0) atomicAdd(&p.table[(uint64_t)kRowLength * p.table_len + len - 1u], 1ull);   // (not expected)
   };
   if ((reinterpret_cast<uintptr_t>(p.lengths) & 15u) == 0) {
@@ -1323,6 +1333,12 @@ __global__ __launch_bounds__(kLenThreads) void short_length_kernel(const HistPar
   }
   if (threadIdx.x == 0 && p.no_adapters && gt10)
     atomicAdd(&p.table[(uint64_t)kRowKmer * p.table_len + 10u], (unsigned long long)gt10);
+}
+
+// starts[i] = (i % per_chunk) * stride: a strided batch restated as gapped ones (launch geometries
+// the strided kernel variant is not built for; every chunk of per_chunk reads is addressed from its own base)
+__global__ __launch_bounds__(256) void strided_starts_kernel(unsigned long long *starts, uint64_t n, uint64_t per_chunk, uint32_t stride) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) starts[i] = (i % per_chunk) * stride;
 }
 
 // dst += src over the planar tables of two accumulators on the same device

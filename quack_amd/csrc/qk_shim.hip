@@ -100,6 +100,8 @@ struct qk_accum {
   unsigned queue_seq = 0;
   uint32_t *d_hit_scratch = nullptr;  // first-hit buffer for device submits
   uint64_t hit_scratch_reads = 0;
+  unsigned long long *d_starts_scratch = nullptr;   // strided batches restated as gapped ones (see enqueue_batch)
+  uint64_t starts_scratch_reads = 0;
   // launches of one accumulator run in submission order even when they come
   // from different streams: they share the queue ring, the first-hit scratch
   // and the table's flush targets
@@ -119,7 +121,7 @@ struct qk_accum {
   uint64_t timing_seq = 0;
   std::vector<TimedLaunch> timed;
   std::vector<hipEvent_t> event_pool;
-  double timing_ms = 0, timing_batch_ms = 0;
+  double timing_ms = 0, timing_batch_ms = 0, timing_min_ms = 0, timing_max_ms = 0;
   uint64_t timing_launches = 0;
 };
 
@@ -460,7 +462,35 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
                  d_off && d_len && (flags & QK_BATCH_ALIGNED128), &pl, (((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) == 0,
                  strided);
   if (rc) return rc;
-  if (strided && !pl.aligned) return fail(QK_EINVAL, "strided batches run with the planner's own launch geometry only");
+  if (strided) {
+    // The strided kernel variant exists for the planner's own geometry only.  Under a tuning override
+    // (QUACK_HIP_THREADS / _UNROLL / _PIPE / _NO_ALIGN4 / _ADAPT_PD / _ADAPT_U, qk_accum_configure) the same
+    // reads run as gapped batches — starts[i] = i * stride written by a small kernel, lengths[] as they are —
+    // in chunks below the 2 GiB a gapped batch may span.  Same counters, the ragged kernels' speed.
+    const bool native = pl.aligned && a->threads == 1024 && pl.pipe == 2 && pl.unroll == (pl.fused_adapters ? 2 : 1);
+    if (!native) {
+      if (a->starts_scratch_reads < n_reads) {
+        QK_HIP(hipDeviceSynchronize());
+        if (a->d_starts_scratch) QK_HIP(hipFree(a->d_starts_scratch));
+        a->d_starts_scratch = nullptr;
+        a->starts_scratch_reads = 0;
+        QK_HIP(hipMalloc((void **)&a->d_starts_scratch, n_reads * sizeof(unsigned long long)));
+        a->starts_scratch_reads = n_reads;
+      }
+      if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));   // the scratch is shared by the accumulator's launches
+      const uint64_t per_chunk = std::max<uint64_t>(1, 0x7FFFFF00ull / stride);
+      const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, 4096);
+      hipLaunchKernelGGL(qk::strided_starts_kernel, dim3(blocks), dim3(256), 0, st, a->d_starts_scratch, n_reads, per_chunk, stride);
+      QK_HIP(hipGetLastError());
+      for (uint64_t lo = 0; lo < n_reads; lo += per_chunk) {
+        const uint64_t cnt = std::min<uint64_t>(per_chunk, n_reads - lo);
+        rc = enqueue_batch(a, d_seq + lo * stride, d_qual + lo * stride, (const uint64_t *)a->d_starts_scratch + lo,
+                           d_hit ? d_hit + lo : nullptr, cnt, cnt * (uint64_t)stride, max_len, st, d_len + lo, 0, 0);
+        if (rc) return rc;
+      }
+      return QK_OK;
+    }
+  }
   if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));
   TimedLaunch tl{};
   // (events around a launch cost ~10 us of stream time: a caller that also measures its own wall
@@ -489,7 +519,8 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.stage_reads = pl.stage_reads;
   hp.status = a->d_status;
   hp.check_aligned = (d_off && d_len && (flags & QK_BATCH_ALIGNED128)) ? 1u : 0u;
-  if (hp.check_aligned) a->status_armed = true;
+  hp.len_limit = strided ? max_len : 0u;
+  if (hp.check_aligned || strided) a->status_armed = true;   // (strided: the length kernel vets lengths[])
   hp.table = a->d_table;
   hp.no_adapters = a->adapters ? 0 : 1;
   hp.first_hit = d_hit;
@@ -612,6 +643,8 @@ int drain_timing(qk_accum *a) {
     if (tl.b0 != tl.t0) QK_HIP(hipEventElapsedTime(&bms, tl.b0, tl.b1));
     a->timing_ms += ms;
     a->timing_batch_ms += bms;
+    if (a->timing_launches == 0 || ms < a->timing_min_ms) a->timing_min_ms = ms;
+    if (a->timing_launches == 0 || ms > a->timing_max_ms) a->timing_max_ms = ms;
     a->timing_launches += 1;
     a->event_pool.push_back(tl.t0);
     a->event_pool.push_back(tl.t1);
@@ -640,7 +673,11 @@ int set_device(const qk_accum *a) {
 // different order on different devices, are the classic multi-communicator hangs.
 // Communicators are created once per device set and kept for the life of the
 // process (a file pair would otherwise pay the ~100 ms of ncclCommInitAll twice).
-typedef struct ncclComm *ncclComm_t;
+// <rccl/rccl.h> is included for its DECLARATIONS only — librccl.so is still loaded with dlopen on first use,
+// so a single-GPU run never maps it — and the values and signatures the dlsym'd pointers below are called
+// with are checked against it at compile time.
+#include <rccl/rccl.h>
+#include <type_traits>
 namespace {
 struct RcclApi {
   int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
@@ -648,10 +685,20 @@ struct RcclApi {
   int (*GroupStart)(void) = nullptr;
   int (*GroupEnd)(void) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int *) = nullptr;
   char why[256] = "";
   bool ok = false;
 };
 constexpr int kNcclUint64 = 5, kNcclSum = 0;   // rccl.h: ncclUint64 = 5 (ncclDataType_t), ncclSum = 0 (ncclRedOp_t)
+static_assert((int)ncclUint64 == kNcclUint64 && (int)ncclSum == kNcclSum && (int)ncclSuccess == 0,
+              "RCCL enum values changed: the all-reduce of the counter tables would run with the wrong type or operator");
+static_assert(sizeof(ncclDataType_t) == sizeof(int) && sizeof(ncclRedOp_t) == sizeof(int) && sizeof(ncclResult_t) == sizeof(int),
+              "RCCL enums are no longer int-sized: the dlsym'd signatures below pass them as int");
+static_assert(std::is_same<decltype(&ncclAllReduce), ncclResult_t (*)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)>::value &&
+              std::is_same<decltype(&ncclCommInitAll), ncclResult_t (*)(ncclComm_t *, int, const int *)>::value &&
+              std::is_same<decltype(&ncclGetErrorString), const char *(*)(ncclResult_t)>::value &&
+              std::is_same<decltype(&ncclGetVersion), ncclResult_t (*)(int *)>::value,
+              "RCCL prototypes differ from the ones rccl_api() casts its dlsym results to");
 
 RcclApi g_rccl;
 std::once_flag g_rccl_once;
@@ -672,6 +719,7 @@ const RcclApi &rccl_api() {
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(lib, "ncclGroupStart");
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(lib, "ncclGroupEnd");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(lib, "ncclGetVersion");   // (optional: diagnostics only)
     if (!g_rccl.CommInitAll || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.GetErrorString) {
       snprintf(g_rccl.why, sizeof g_rccl.why, "librccl.so lacks a required symbol");
       return;
@@ -718,6 +766,13 @@ int rccl_sum_tables(qk_accum **who, int n, size_t words) {
     std::vector<ncclComm_t> comms(n);
     const int e = api.CommInitAll(comms.data(), n, devs.data());
     if (e) return fail(QK_ERCCL, "ncclCommInitAll: %s", api.GetErrorString(e));
+    if (getenv("QUACK_VERBOSE")) {
+      int v = 0;
+      if (api.GetVersion) (void)api.GetVersion(&v);
+      fprintf(stderr, "[quack] RCCL %d (built against %d): %d communicators, devices", v, NCCL_VERSION_CODE, n);
+      for (int i = 0; i < n; ++i) fprintf(stderr, " %d", devs[i]);
+      fprintf(stderr, "; all-reduce(SUM, u64) of %zu words\n", words);
+    }
     it = g_rccl_comms.emplace(devs, std::move(comms)).first;
   }
   const std::vector<ncclComm_t> &comms = it->second;
@@ -886,6 +941,7 @@ void qk_accum_destroy(qk_accum *a) {
   if (a->d_order) (void)hipFree(a->d_order);
   if (a->d_reach) (void)hipFree(a->d_reach);
   if (a->d_hit_scratch) (void)hipFree(a->d_hit_scratch);
+  if (a->d_starts_scratch) (void)hipFree(a->d_starts_scratch);
   if (a->d_kmer_bits) (void)hipFree(a->d_kmer_bits);
   if (a->d_kmer_filter) (void)hipFree(a->d_kmer_filter);
   if (a->d_kmer_buckets) (void)hipFree(a->d_kmer_buckets);
@@ -1260,6 +1316,8 @@ int qk_accum_sync(qk_accum *a) {
     a->status_armed = false;
     if (st) {
       QK_HIP(hipMemset(a->d_status, 0, sizeof st));
+      if (st & qk::kStatusBadLength)
+        return fail(QK_EINVAL, "a strided batch holds a read longer than its stride; the counters are unusable");
       return fail(QK_EINVAL, "a batch submitted as QK_BATCH_ALIGNED128 holds a read that does not start on a 128-byte boundary; the counters are unusable");
     }
   }
@@ -1414,12 +1472,22 @@ int qk_accum_timing_enable(qk_accum *a, int on) {
   a->timing_seq = 0;
   a->timing_ms = 0;
   a->timing_batch_ms = 0;
+  a->timing_min_ms = a->timing_max_ms = 0;
   a->timing_launches = 0;
   return QK_OK;
 }
 
 int qk_accum_timing_read(qk_accum *a, double *total_ms, uint64_t *launches) {
   return qk_accum_timing_read_batch(a, total_ms, nullptr, launches);
+}
+
+int qk_accum_timing_read_range(qk_accum *a, double *hist_min_ms, double *hist_max_ms) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  int rc = drain_timing(a);
+  if (rc) return rc;
+  if (hist_min_ms) *hist_min_ms = a->timing_min_ms;
+  if (hist_max_ms) *hist_max_ms = a->timing_max_ms;
+  return QK_OK;
 }
 
 int qk_accum_timing_read_batch(qk_accum *a, double *hist_ms, double *batch_ms, uint64_t *launches) {

@@ -53,6 +53,13 @@ typedef struct {
   uint32_t *piece_crc;
   unsigned n, cap;
 } qkh_end_list;
+/* A decoder call ends when its trailer log is full.  If that call produced nothing — 64 members in a
+ * row without a byte of output between them — it returns 0 without the stream being over: the caller
+ * takes the log and calls again (zlib's gzread, which the reference reads through, walks through any
+ * number of empty members). */
+static inline int qkh_inflate_log_full(const qkh_inflate *z) {
+  return z->tl_n == QKH_TRAILER_LOG && z->state != QKH_Z_DONE && z->state != QKH_Z_ERROR;
+}
 /* append the trailers the last decoder call logged; `before` = chunk bytes produced before that call */
 int qkh_end_list_take(qkh_end_list *l, const qkh_inflate *z, size_t before);
 /* fill piece_crc[0..n] from the chunk's final bytes */

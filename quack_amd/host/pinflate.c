@@ -244,7 +244,8 @@ static void *worker_main(void *arg) {
           long got = qkh_inflate_read(z, s->b8 + WIN + n, s->cap8 - n, p->chain_win_len + n);
           if (qkh_end_list_take(&s->el, z, n)) failed = 1;
           if (got > 0) n += (size_t)got;
-          if (z->stopped || z->state == QKH_Z_DONE || z->state == QKH_Z_ERROR || got <= 0) break;
+          if (z->stopped || z->state == QKH_Z_DONE || z->state == QKH_Z_ERROR) break;
+          if (got <= 0 && !(got == 0 && qkh_inflate_log_full(z))) break;   /* (a full trailer log is not the end) */
           if (n >= p->inorder_max) {   /* enough for one slot: the rest of the stream goes to the serial producer */
             overflow = 1;
             break;
@@ -410,6 +411,14 @@ int qkh_pinflate_handoff(qkh_pinflate *p, qkh_inflate *z, uint8_t *window, size_
   }
   pthread_mutex_unlock(&p->mu);
   return h;
+}
+
+int qkh_pinflate_failed(qkh_pinflate *p) {
+  int f;
+  pthread_mutex_lock(&p->mu);
+  f = p->failed;
+  pthread_mutex_unlock(&p->mu);
+  return f;
 }
 
 void qkh_pinflate_stats(const qkh_pinflate *p, unsigned *kept, unsigned *redone) {

@@ -24,6 +24,9 @@ void qkh_pinflate_lines(qkh_pinflate *p, const uint32_t **nl, size_t *n);
  * exact point with the window's last *window_len bytes (<= 32768) as history: the caller goes on
  * with the constant-memory serial producer. */
 int qkh_pinflate_handoff(qkh_pinflate *p, qkh_inflate *z, uint8_t *window, size_t *window_len);
+/* 1 when a worker could not allocate what the in-order decode of a slice needs: the stream then ends
+ * early, and the caller must report that instead of taking it for the end of the file */
+int qkh_pinflate_failed(qkh_pinflate *p);
 /* slices whose speculative decode was kept / that were decoded again in order */
 void qkh_pinflate_stats(const qkh_pinflate *p, unsigned *kept, unsigned *redone);
 void qkh_pinflate_close(qkh_pinflate *p);

@@ -366,6 +366,10 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
     turn = (turn + 1) % n_devices;
   }
   t_parsed = now_s();
+  if (qkh_reader_failed(rd)) {
+    host_fail("%s: out of memory while reading", path);
+    goto out;
+  }
   if (n_devices > 1 && qk_accum_allreduce(accs, n_devices)) {
     host_fail("%s", qk_last_error());
     goto out;

@@ -57,6 +57,9 @@ int64_t qkh_reader_fill_strided(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint
 uint64_t qkh_reader_parked_len(const qkh_reader *r);
 /* 1 once the stream is exhausted (or stopped by a malformed record) */
 int qkh_reader_done(const qkh_reader *r);
+/* 1 when the stream ended because a decoder thread ran out of memory, not because the file did:
+ * the counts so far are those of a truncated stream and must not be reported */
+int qkh_reader_failed(const qkh_reader *r);
 
 /* ---- adapters ------------------------------------------------------------ */
 /* bitset: QK_KMER_TABLE_WORDS words, bit i <=> kmers[i] = 1 (quack.c:171) */

@@ -212,6 +212,8 @@ void qkh_reader_close(qkh_reader *r) {
   free(r);
 }
 
+int qkh_reader_failed(const qkh_reader *r) { return qkh_source_failed(r->src); }
+
 int qkh_reader_done(const qkh_reader *r) { return r->finished && !r->have_parked; }
 
 /* The common case without the general machinery: a four-line FASTQ record
@@ -427,6 +429,7 @@ int qkh_read_adapters(const char *path, uint32_t *bitset) {
   }
   free(s);
   free(q);
+  const int failed = qkh_reader_failed(r);   /* a decoder thread out of memory: not the file's end */
   qkh_reader_close(r);
-  return 0;
+  return failed ? -1 : 0;
 }

@@ -37,10 +37,12 @@
  * To be able to take those bytes back, the last 32 KiB of every chunk are
  * handed out together with the next chunk.
  */
+#define _GNU_SOURCE   /* sched_getaffinity, CPU_COUNT */
 #include "source.h"
 
 #include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -166,10 +168,18 @@ struct qkh_source {
   int have_lines;           /* ... and whether it is complete (every chunk so far came with an index) */
   const uint32_t *plain_nl; /* no trailer checks (plain files): the current block's own index */
   size_t plain_n_nl;
+  int oom;                  /* a producer thread could not allocate: see producer_oom */
   int plain_pool;           /* uncompressed regular file: workers pread() the blocks (and index their lines) */
   uint64_t file_len;
   size_t given;             /* bytes of the current chunk handed to the caller */
 };
+
+/* A producer ran out of memory: the stream ends where it stands, and qkh_source_failed() tells the reader
+ * that this end is not the file's (the run must fail, not report the counts of a truncated stream). */
+static size_t producer_oom(qkh_source *s) {
+  __atomic_store_n(&s->oom, 1, __ATOMIC_RELAXED);
+  return 0;
+}
 
 /* ------------------------------------------------------------- ring basics */
 static block *claim_block(qkh_source *s) { /* producer side; NULL when closing */
@@ -204,12 +214,14 @@ static size_t fill_serial(qkh_source *s, block *b) {
     long k = 1;
     memcpy(b->data - s->hist_len, s->hist, s->hist_len);
     b->el.n = 0;
-    while (got < BLOCK_BYTES && (k = qkh_inflate_read(s->zf, b->data + got, BLOCK_BYTES - got, s->hist_len + got)) > 0) {
-      if (qkh_end_list_take(&b->el, s->zf, got)) return 0;
-      got += (size_t)k;
+    while (got < BLOCK_BYTES) {
+      k = qkh_inflate_read(s->zf, b->data + got, BLOCK_BYTES - got, s->hist_len + got);
+      /* (also the trailers met by a call that produced nothing) */
+      if (qkh_end_list_take(&b->el, s->zf, got)) return producer_oom(s);
+      if (k > 0) got += (size_t)k;
+      else if (!(k == 0 && qkh_inflate_log_full(s->zf))) break;
     }
-    if (k <= 0 && qkh_end_list_take(&b->el, s->zf, got)) return 0;   /* (a trailer met by a call that produced nothing) */
-    if (qkh_end_list_crcs(&b->el, b->data, got)) return 0;
+    if (qkh_end_list_crcs(&b->el, b->data, got)) return producer_oom(s);
     b->n_nl = qkh_index_lines(b->data, got, &b->nl, &b->cap_nl);
     if (got >= HIST) {
       memcpy(s->hist, b->data + got - HIST, HIST);
@@ -258,6 +270,8 @@ static int start_serial_after_pgzip(qkh_source *s) {
   qkh_inflate *z = malloc(sizeof *z);
   uint8_t *hist = malloc(HIST);
   size_t hist_len = 0;
+  if (qkh_pinflate_failed(s->pz)) (void)producer_oom(s);   /* (asked before the decoder is closed below) */
+  if (!z || !hist) (void)producer_oom(s);
   if (!z || !hist || !qkh_pinflate_handoff(s->pz, z, hist, &hist_len)) {
     free(z);
     free(hist);
@@ -270,9 +284,9 @@ static int start_serial_after_pgzip(qkh_source *s) {
   s->hist_len = hist_len;
   s->n_ring = SERIAL_RING;
   s->ring = calloc(s->n_ring, sizeof *s->ring);
-  if (!s->ring) return 0;
+  if (!s->ring) return (int)producer_oom(s);
   for (unsigned i = 0; i < s->n_ring; i++) {
-    if (!(s->ring[i].base = malloc(HIST + BLOCK_BYTES))) return 0;
+    if (!(s->ring[i].base = malloc(HIST + BLOCK_BYTES))) return (int)producer_oom(s);
     s->ring[i].data = s->ring[i].base + HIST;
   }
   if (pthread_create(&s->threads[0], NULL, serial_main, s)) return 0;
@@ -405,12 +419,20 @@ static void *bgzf_worker_main(void *arg) {
         got += (size_t)k;
     } else {
       qkh_inflate_init(z, b->in, b->in_len);
-      while (got < BLOCK_BYTES && (k = qkh_inflate_read(z, b->data + got, BLOCK_BYTES - got, got)) > 0) {
-        if (qkh_end_list_take(&b->el, z, got)) break;
-        got += (size_t)k;
+      int oom = 0;
+      while (got < BLOCK_BYTES && !oom) {
+        k = qkh_inflate_read(z, b->data + got, BLOCK_BYTES - got, got);
+        oom = qkh_end_list_take(&b->el, z, got);
+        if (k > 0) got += (size_t)k;
+        else if (!(k == 0 && qkh_inflate_log_full(z))) break;
       }
-      if (k <= 0) (void)qkh_end_list_take(&b->el, z, got);
-      (void)qkh_end_list_crcs(&b->el, b->data, got);
+      if (!oom) oom = qkh_end_list_crcs(&b->el, b->data, got);
+      if (oom) {   /* the block's member ends / CRCs are incomplete: the stream ends in front of it, with an error */
+        (void)producer_oom(s);
+        got = 0;
+        b->el.n = 0;
+        b->expect = (size_t)-1;
+      }
     }
     b->n_nl = qkh_index_lines(b->data, got, &b->nl, &b->cap_nl);
     pthread_mutex_lock(&s->mu);
@@ -422,11 +444,63 @@ static void *bgzf_worker_main(void *arg) {
 }
 
 /* --------------------------------------------------------------------- API */
+/* GPUs of this node as the kernel driver lists them (KFD topology nodes with SIMDs), narrowed by
+ * HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES — read from sysfs: asking the HIP runtime would start it
+ * (0.15-0.3 s) on the thread that is about to parse. */
+static int visible_gpus(void) {
+  int n = 0;
+  for (int node = 0; node < 64; node++) {
+    char path[96], line[128];
+    snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", node);
+    FILE *f = fopen(path, "r");
+    if (!f) break;
+    while (fgets(line, sizeof line, f)) {
+      long v;
+      if (sscanf(line, "simd_count %ld", &v) == 1 && v > 0) n++;
+    }
+    fclose(f);
+  }
+  for (int k = 0; k < 2; k++) {
+    const char *e = getenv(k ? "ROCR_VISIBLE_DEVICES" : "HIP_VISIBLE_DEVICES");
+    if (e && *e) {
+      int listed = 1;
+      for (const char *c = e; *c; c++) listed += *c == ',';
+      if (n == 0 || listed < n) n = listed;
+    }
+  }
+  return n > 0 ? n : 1;
+}
+
+/* Decoder threads.  QUACK_THREADS, or this process's share of the host: the cores it may run on (affinity
+ * mask, cgroup v2 CPU quota) divided by the node's GPUs — a node feeds one quack per GPU — and at most
+ * MAX_WORKERS = 32 (round 2 capped at 16: the 1.8-Gbase file took 0.96-1.17 s with 16 threads, 0.50-0.58 s
+ * with 32 on a 256-thread / 8-GPU host). */
 static int n_cpus(void) {
-  long n = sysconf(_SC_NPROCESSORS_ONLN);
+  static int cached;
   const char *e = getenv("QUACK_THREADS");
-  if (e && atoi(e) > 0) n = atoi(e);
-  else if (n > 16) n = 16; /* the GPU box's share for one GPU */
+  long n;
+  if (e && atoi(e) > 0) {
+    n = atoi(e);
+  } else {
+    if (cached) return cached;
+    n = sysconf(_SC_NPROCESSORS_ONLN);
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+      long quota, period;
+      if (fscanf(f, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0 && (quota + period - 1) / period < n)
+        n = (quota + period - 1) / period;
+      fclose(f);
+    }
+#endif
+    n /= visible_gpus();
+    if (n < 1) n = 1;
+    if (n > MAX_WORKERS) n = MAX_WORKERS;
+    cached = (int)n;
+    return cached;
+  }
   if (n < 1) n = 1;
   if (n > MAX_WORKERS) n = MAX_WORKERS;
   return (int)n;
@@ -724,6 +798,10 @@ int qkh_source_lines(qkh_source *s, const uint32_t **nl, size_t *n) {
 }
 
 const char *qkh_source_kind(const qkh_source *s) { return s->kind; }
+
+int qkh_source_failed(const qkh_source *s) {
+  return __atomic_load_n(&s->oom, __ATOMIC_RELAXED) || (s->pz && qkh_pinflate_failed(s->pz));
+}
 
 void qkh_source_close(qkh_source *s) {
   if (!s) return;

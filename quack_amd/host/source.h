@@ -16,6 +16,9 @@ int qkh_source_next(qkh_source *s, const uint8_t **data, size_t *len);
  * its data pointer — indexed by the producer threads.  Returns 0 when there is no index for this block
  * (zlib / plain producers, the last few bytes of a stream): the caller looks for the lines itself. */
 int qkh_source_lines(qkh_source *s, const uint32_t **nl, size_t *n);
+/* 1 when a producer thread ran out of memory: the stream ended early for that reason, not because the
+ * file did — the caller must fail instead of reporting a truncated stream's counts. */
+int qkh_source_failed(const qkh_source *s);
 void qkh_source_close(qkh_source *s);
 /* "zlib", "inflate_fast", "bgzf xN" or "plain": which producer is running */
 const char *qkh_source_kind(const qkh_source *s);

@@ -1,7 +1,8 @@
 """BASELINE.json configurations at full size on one MI355X, device-resident
-(generated on the GPU), checked through size-independent properties and — the
-oracle manages ~0.25 Gbases/s on one core — exactly against the oracle for
-config 2 and config 5."""
+(generated on the GPU), checked through size-independent properties and exactly against the oracle —
+every read of configs 2, 3, 5, of config 4's per-GPU share and of the trimmed-reads
+workload (the oracle manages ~0.25 Gbases/s per core; it runs on up to 32 threads,
+one table each, summed)."""
 import numpy as np
 import pytest
 
@@ -48,33 +49,70 @@ def test_config2_10M_x_150_exact_and_properties():
     sd2 = run_device(seq, qual, None, n, n * L, L, passes=2)
     np.testing.assert_array_equal(sd2.bases, 2 * sd.bases)
     # exact, against the oracle on the same bytes
-    want, wn = ob.accumulate_batch(seq[:n * L].cpu().numpy(), qual[:n * L].cpu().numpy(), read_len=L)
+    want, wn = ob.accumulate_batch_threads(seq[:n * L].cpu().numpy(), qual[:n * L].cpu().numpy(), read_len=L)
     assert wn == n
     np.testing.assert_array_equal(sd.bases, want)
 
 
-def test_config3_10M_x_300_adapters_properties_and_sampled_exact():
-    n, L = 10_000_000, 300
-    ads = synth.synthetic_adapters()
-    k = ob.kmers_from_seqs(ads)
-    bits = ob.kmers_to_bitset(k)
-    seq, qual = device_fixed(n, L, seed=3)
-    # splice adapters into 25 % of the reads of the first 2M on the host, upload
-    m = 2_000_000
-    head = synth.splice_adapters(seq[:m * L].cpu().numpy(), L, ads, seed=33)
-    seq[:m * L] = torch.from_numpy(head).cuda()
-    sd = run_device(seq, qual, None, n, n * L, L, bits)
-    b = sd.bases.astype(np.int64)
+def test_config3_10M_x_300_adapters_exact_on_every_read():
+    """the bench's own config-3 batch (bench.make_batch: 25 % of the reads carry a spliced adapter, seed 3): properties,
+    and every counter against the oracle over ALL 10M reads (round 2 checked 2M and took the rest by additivity)"""
+    import bench
+    w = dict(bench.WORKLOADS["cfg3"])
+    n, L = w["n"], w["L"]
+    bits, ads = bench.synthetic_adapter_bits(np)
+    k = ob.kmers_from_seqs([bytes(a) for a in ads])
+    assert np.array_equal(ob.kmers_to_bitset(k), bits)          # the product's read_adapters rule == the oracle's
+    b = bench.make_batch(torch, np, w, seed=3, device=torch.device("cuda", 0), ads=ads)
+    assert 0.2 * n < b["spliced"] < 0.3 * n
+    sd = run_device(b["seq"], b["qual"], None, n, n * L, L, bits)
+    t = sd.bases.astype(np.int64)
     assert sd.number_of_sequences == n and sd.max_length == L
-    assert (b[:, :91].sum(axis=1) == n).all() and (b[:, 91:95].sum(axis=1) == n).all()
-    assert b[L - 1, 95] == n
-    assert 0 < b[:, 96].sum() <= n and b[:10, 96].sum() == 0     # at most one first hit per read, never before 10
-    # the first 2M reads exactly; the remainder through additivity
-    head_t = run_device(seq, qual, None, m, m * L, L, bits)
-    want, _ = ob.accumulate_batch(head, qual[:m * L].cpu().numpy(), read_len=L, kmers=k)
-    np.testing.assert_array_equal(head_t.bases, want)
-    tail_t = run_device(seq[m * L:], qual[m * L:], None, n - m, (n - m) * L, L, bits)
-    np.testing.assert_array_equal(head_t.bases + tail_t.bases, sd.bases)
+    assert (t[:, :91].sum(axis=1) == n).all() and (t[:, 91:95].sum(axis=1) == n).all()
+    assert t[L - 1, 95] == n
+    assert 0.2 * n < t[:, 96].sum() <= n and t[:10, 96].sum() == 0     # at most one first hit per read, never before 10
+    want, wn = ob.accumulate_batch_threads(b["seq"][:n * L].cpu().numpy(), b["qual"][:n * L].cpu().numpy(), read_len=L, kmers=k)
+    assert wn == n
+    np.testing.assert_array_equal(sd.bases, want)
+
+
+def test_trimmed_10M_strided_exact_on_every_read():
+    """the bench's trimmed-reads batch (70 % full length, the rest 120-149, stride 152 + lengths[]) against the
+    oracle on the same reads packed"""
+    import bench
+    w = dict(bench.WORKLOADS["trimmed"])
+    b = bench.make_batch(torch, np, w, seed=7, device=torch.device("cuda", 0))
+    with quack_amd.Accumulator(0) as acc:
+        acc.submit_device_strided(b["seq"], b["qual"], b["d_len"], b["n"], b["stride"], b["max_len"])
+        sd = acc.finish()
+    hs, hq, off, m, bases = bench.host_sample(np, b, w, 1 << 62)
+    assert m == b["n"] and bases == b["total"]
+    want, wn = ob.accumulate_batch_threads(hs, hq, off)
+    assert wn == b["n"] and sd.number_of_sequences == wn
+    np.testing.assert_array_equal(sd.bases, want)
+
+
+def test_config4_full_per_gpu_share_each_mate_exact():
+    """config 4 (paired 2 x 50M x 150 bp over 8 GPUs) as far as one GPU goes: its full per-GPU share — 2 x 6.25M
+    reads, R2 qualities in [2,30], seeds 4 / 5 — through the bench's path: two accumulators fed from ONE stream,
+    three steps; each mate against the oracle (x3: the counters are linear in the passes).  quack.c:911-921."""
+    import bench
+    w = dict(bench.WORKLOADS["cfg4"])
+    n, L = w["n"], w["L"]
+    dev = torch.device("cuda", 0)
+    f = bench.make_batch(torch, np, w, seed=4, device=dev)
+    r = bench.make_batch(torch, np, w, seed=5, device=dev, q_hi_override=30)
+    side = torch.cuda.Stream(dev)
+    with quack_amd.Accumulator(0, None, max_len_hint=L) as fa, quack_amd.Accumulator(0, None, max_len_hint=L) as ra:
+        for _ in range(3):
+            fa.submit_device(f["seq"], f["qual"], None, n, n * L, L, stream=side.cuda_stream)
+            ra.submit_device(r["seq"], r["qual"], None, n, n * L, L, stream=side.cuda_stream)
+        fsd, rsd = fa.finish(), ra.finish()
+    for sd, b in ((fsd, f), (rsd, r)):
+        want, wn = ob.accumulate_batch_threads(b["seq"][:n * L].cpu().numpy(), b["qual"][:n * L].cpu().numpy(), read_len=L)
+        assert wn == n and sd.number_of_sequences == 3 * n
+        np.testing.assert_array_equal(sd.bases, 3 * want)
+    assert rsd.bases[:, 31:91].sum() == 0 and fsd.bases[:, 31:42].sum() > 0      # R2's qualities stop at Q30
 
 
 def test_config5_ragged_1kb_to_20kb_exact():
@@ -96,7 +134,7 @@ def test_config5_ragged_1kb_to_20kb_exact():
     cover = n - np.searchsorted(np.sort(lens), np.arange(sd.max_length), side="right")   # reads longer than pos
     assert (b[:, :91].sum(axis=1) == cover).all() and (b[:, 91:95].sum(axis=1) == cover).all()
     assert (b[:, 95] == np.bincount(lens - 1, minlength=sd.max_length)).all()
-    want, _ = ob.accumulate_batch(seq[:total].cpu().numpy(), qual[:total].cpu().numpy(), off)
+    want, _ = ob.accumulate_batch_threads(seq[:total].cpu().numpy(), qual[:total].cpu().numpy(), off)
     np.testing.assert_array_equal(sd.bases, want)
 
 

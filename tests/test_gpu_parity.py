@@ -702,6 +702,65 @@ def test_strided_rejects_bad_geometry():
             acc.submit_strided(np.zeros(24, np.uint8), np.zeros(24, np.uint8), np.array([3, 9, 3], np.uint32), 8)    # read > stride
 
 
+@pytest.mark.parametrize("cfg,env", [(dict(threads=512), {}), (dict(unroll=2), {}), (dict(threads=256, unroll=2, tile=64), {}),
+                                     ({}, {"QUACK_HIP_PIPE": "1"}), ({}, {"QUACK_HIP_NO_ALIGN4": "1"}),
+                                     ({}, {"QUACK_HIP_ADAPT_PD": "3"}), ({}, {"QUACK_HIP_UNFUSED_ADAPTERS": "1"})])
+def test_strided_batches_under_tuning_overrides(cfg, env, monkeypatch):
+    """the strided kernel variant exists for the planner's own geometry; under an override the same reads run as
+    gapped batches (starts written on the device) — round 2 failed with QK_EINVAL here, and so did the CLI on
+    any trimmed FASTQ with such a knob set"""
+    import torch
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    n, stride = 20000, 152
+    seq, qual, off = synth.ragged(n, 100, 150, seed=77, q_lo=1, q_hi=60, alphabet=b"ACGTNacgt")
+    seq = seq.copy()
+    rng = np.random.default_rng(5)
+    for r in rng.integers(0, n, n // 4):                # an adapter somewhere in a quarter of the reads
+        a, e = int(off[r]), int(off[r + 1])
+        ad = np.frombuffer(ads[r % len(ads)], np.uint8)
+        at = a + int(rng.integers(0, e - a - 10))
+        m = min(len(ad), e - at)
+        seq[at:at + m] = ad[:m]
+    s2, q2, lens = strided_from_ragged(seq, qual, off, stride)
+    for kmers, bits in ((None, None), (k, ob.kmers_to_bitset(k))):
+        want = ob.accumulate_batch(seq, qual, off, kmers=kmers)
+        with quack_amd.Accumulator(0, bits) as acc:
+            if cfg:
+                acc.configure(**cfg)
+            acc.submit_strided(s2, q2, lens, stride)
+            d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+            d_l = torch.from_numpy(lens.astype(np.int32)).cuda()
+            acc.submit_device_strided(d_s, d_q, d_l, n, stride, int(lens.max()))
+            sd = acc.finish()
+        assert sd.number_of_sequences == 2 * want[1]
+        assert_same((sd.bases, want[1]), (2 * want[0], want[1]))
+
+
+def test_device_side_length_beyond_the_declared_maximum_is_reported():
+    """lengths[] of a device-resident strided batch cannot be vetted by the host: a read longer than the caller
+    declared must fail the next sync, and must not write outside the table"""
+    import torch
+    n, stride = 5000, 152
+    s2 = np.full(n * stride, ord("A"), np.uint8)
+    q2 = np.full(n * stride, 70, np.uint8)
+    lens = np.full(n, 100, np.int32)
+    lens[1234] = 140          # within the stride, beyond max_len = 100
+    with quack_amd.Accumulator(0, max_len_hint=100) as acc:
+        d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+        acc.submit_device_strided(d_s, d_q, torch.from_numpy(lens).cuda(), n, stride, 100)
+        with pytest.raises(quack_amd.HipUnavailable, match="longer than"):
+            acc.sync()
+    lens[1234] = 100000       # beyond everything
+    with quack_amd.Accumulator(0, max_len_hint=100) as acc:
+        d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+        acc.submit_device_strided(d_s, d_q, torch.from_numpy(lens).cuda(), n, stride, 100)
+        with pytest.raises(quack_amd.HipUnavailable, match="longer than"):
+            acc.sync()
+
+
 def test_host_feed_lays_trimmed_reads_out_at_a_fixed_stride(tmp_path, monkeypatch):
     """whole-file path on short reads of nearly one length: from the second batch on the tokenizer writes
     them at a fixed stride (qk_accum_commit_strided); same counters as the oracle, as the packed feed

@@ -366,3 +366,31 @@ def test_a_slice_that_outgrows_the_parallel_decoder_is_streamed_by_the_serial_on
     monkeypatch.setenv("QUACK_ZLIB", "1")
     _, ref = source_bytes(str(p))
     assert par == ref and len(ref) < len(text)
+
+
+def test_long_runs_of_empty_members_do_not_end_the_stream(tmp_path, monkeypatch):
+    """zlib's gzread — the reference's reader — walks through any number of empty members; the decoders log at
+    most 64 trailers per call, and a call that only met trailers returns 0 without being the end (ADVICE round 2:
+    the callers took that 0 for the end of the stream)"""
+    a, b, c = fastq(300, 150), fastq(200, 100), fastq(50, 75)
+    empty = gz(b"")
+    for run in (63, 64, 65, 200):
+        p = tmp_path / ("e%d.fq.gz" % run)
+        p.write_bytes(empty * run + gz(a) + empty * run + gz(b) + empty * (2 * run + 1) + gz(c) + empty * run)
+        want = a + b + c
+        assert gzip.open(str(p)).read() == want
+        for env in ({"QUACK_NO_PGZIP": "1"}, {"QUACK_THREADS": "4", "QUACK_PGZIP_CHUNK_KB": "8"}, {"QUACK_ZLIB": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            kind, got = source_bytes(str(p))
+            for k in env:
+                monkeypatch.delenv(k)
+            assert got == want, (run, kind, len(got), len(want))
+        # the same as BGZF blocks (htslib writes an empty block at the end of every file: `cat` of many small files)
+        pb = tmp_path / ("e%d.bgzf.gz" % run)
+        eof_block = bgzf(b"", eof=False) if False else bgzf(b"")   # one empty block
+        pb.write_bytes(eof_block * run + bgzf(a, eof=False) + eof_block * (run + 3) + bgzf(b, block=1000) + eof_block * run)
+        monkeypatch.setenv("QUACK_THREADS", "3")
+        kind, got = source_bytes(str(pb))
+        monkeypatch.delenv("QUACK_THREADS")
+        assert kind.startswith("bgzf") and got == a + b, (run, kind, len(got))
