@@ -124,6 +124,15 @@ __device__ __forceinline__ u32x3 load12_aligned(const uint8_t *p) {
   return *reinterpret_cast<const u32x3 *>(__builtin_assume_aligned(p, 4));
 }
 
+// 16 bytes from a 4-byte-aligned address: one global_load_dwordx4 (W16 builds: a lane owns two adjacent chunks)
+struct u32x4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ u32x4 load16_aligned(const uint8_t *p) {
+  return *reinterpret_cast<const u32x4 *>(__builtin_assume_aligned(p, 4));
+}
+
+template <bool W16> struct load_reg { using type = u32x3; };
+template <> struct load_reg<true> { using type = u32x4; };
+
 // the 8 bytes that start `s` (0..3) bytes into a 12-byte window
 __device__ __forceinline__ uint2 window8(u32x3 w, uint32_t s) {
   return make_uint2(__builtin_amdgcn_alignbyte(w.y, w.x, s), __builtin_amdgcn_alignbyte(w.z, w.y, s));
@@ -187,9 +196,10 @@ constexpr uint32_t kStageReadsMax = 8192;
 // against the exact table when the queue holds a wave's worth of entries.
 constexpr uint32_t kCandCap = 96;                       // entries per wave: drained above 32, a step adds <= 64
 constexpr uint32_t kCandWords = 16u * kCandCap * 2u;    // 16 waves x 96 entries x 8 bytes = 12 KiB
+constexpr uint32_t kCandWords16 = 16u * kCandCap * 4u;  // W16 builds: one 16-byte entry per LANE (16 positions): 24 KiB
 inline size_t hist_lds_bytes(uint32_t ch, uint32_t replicas, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false,
-                             uint32_t stage_reads = kStageReads) {
-  return ((size_t)kQRows * hist_row_dwords(ch, replicas) + (adapt ? 6u : 5u) * 8u * ch + 4u + (adapt ? kFusedFilterWords + kCandWords : 0u)) * sizeof(uint32_t) +
+                             uint32_t stage_reads = kStageReads, bool w16 = false) {
+  return ((size_t)kQRows * hist_row_dwords(ch, replicas) + (adapt ? 6u : 5u) * 8u * ch + 4u + (adapt ? kFusedFilterWords + (w16 ? kCandWords16 : kCandWords) : 0u)) * sizeof(uint32_t) +
          (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)stage_reads * (adapt ? 12 : 8) : 0);
 }
 
@@ -299,14 +309,25 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 // (SV builds are held to 64 VGPRs: with the tail masks the loop is VALU-heavier than
 // the fixed-length one and gains from two workgroups per CU, 0.61 -> 0.53 ms per 10M
 // trimmed 150 bp reads; the plain fixed-length kernel is faster with one)
-template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false>
+// W16 (round 3; AL builds only): a lane owns TWO adjacent chunks — 16 positions — of a read and fetches them with one
+// global_load_dwordx4 per array.  Measured on loads alone (tools/piece_rate.hip): the long-read pattern — a wave takes
+// a read's 512-byte piece of the tile, the next read lies ~10 kb away — moves 4.8 TB/s with 8 bytes per lane and 5.25
+// with 16 (a contiguous stream: 5.9), whatever the piece size; and every per-lane cost of a step (addresses, the DPP
+// for the predecessor codes, the candidate vote) is paid once per 16 positions.  The LDS image keeps its 8-position
+// chunk layout; only the column order changes (even chunks first, so that the lanes of one counting instruction
+// still touch consecutive dwords).
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false>
 __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
   static_assert(!SV || (FIXED && AL), "strided batches are a variant of the dword-aligned fixed-length path");
+  static_assert(!W16 || (AL && !SV && MODE == 0), "16 positions per lane: dword-aligned batches only");
   constexpr bool STAGED = !FIXED;   // ragged batches: the read list is staged in LDS pass by pass
+  constexpr int K = W16 ? 2 : 1;    // 8-position chunks per lane
+  using LoadT = typename load_reg<W16>::type;
+  constexpr uint32_t kCandWordsT = W16 ? kCandWords16 : kCandWords;
   extern __shared__ uint32_t lds_raw[];
   // ADAPT: the window filter sits first, so that the probes' LDS addresses are
   // "field + constant" (no per-probe add of a layout-dependent base)
-  uint32_t *lds = lds_raw + (ADAPT ? kFusedFilterWords + kCandWords : 0u);
+  uint32_t *lds = lds_raw + (ADAPT ? kFusedFilterWords + kCandWordsT : 0u);
   const uint32_t tid = threadIdx.x;
   const uint32_t CH = p.ch;
   const uint32_t RD = p.row_dwords;
@@ -338,46 +359,57 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   // ADAPT: lanes 0 and 1 of every wave are feeders: they recompute the chunks
   // of the previous wave's lanes 62/63 so that lanes 2/3 find their
   // predecessors' codes by DPP; they take no part in the histograms.
+  // (W16: one feeder lane, the previous wave's lane 63 — 16 positions either way)
   const uint32_t lane_id = tid & 63u;
   const uint32_t lane10 = lane_id << 10;
-  const uint32_t feeders = ADAPT ? 2u : 0u;
+  const uint32_t feeders = ADAPT ? (W16 ? 1u : 2u) : 0u;
   const int32_t slot_signed = (int32_t)((tid >> 6) * (64u - feeders) + lane_id) - (int32_t)feeders;
   const uint32_t slot = slot_signed < 0 ? 0u : (uint32_t)slot_signed;
   // a read row is CH chunk lanes, preceded (ADAPT, several tiles) by two halo
   // lanes that cover the 16 positions in front of the tile: they load and
   // encode like any lane, so that the tile's first chunks find their
   // predecessor codes in lanes -1 / -2, but they count nothing
-  const uint32_t H = ADAPT ? p.halo : 0u;
-  const uint32_t CHW = CH + H;
+  const uint32_t H = ADAPT ? p.halo : 0u;            // (W16: one halo lane)
+  const uint32_t CHW = CH / K + H;                   // lanes per read row
   const uint32_t ri = slot / CHW;
   const uint32_t chh = slot - ri * CHW;
   const bool is_halo = chh < H;
-  const uint32_t ch = is_halo ? 0u : chh - H;        // column used for LDS addressing (halo lanes only ever add pads)
+  const uint32_t chl = is_halo ? 0u : chh - H;       // the lane's place in its read row (halo lanes only ever add pads)
   const int32_t ch_signed = (int32_t)chh - (int32_t)H;
   const uint32_t RW = p.reads_per_iter;
   const bool lane_on = lane_id >= feeders && !is_halo && ri < RW;
+  // the lane's K chunks of the tile and their LDS columns.  W16: chunks 2*chl and 2*chl + 1; the even chunks of a
+  // tile take the first CH/2 columns of a set, the odd ones the second half — the lanes of ONE counting instruction
+  // (same k) then touch consecutive dwords, as they do with one chunk per lane
+  auto lds_col = [&](uint32_t c) { return W16 ? (c >> 1) + (c & 1u) * (CH / 2u) : c; };
+  uint32_t chk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) chk[k] = (uint32_t)K * chl + (uint32_t)k;
   // byte address, in quality row 0, of the counter column this lane's i-th counting
   // instruction adds to (see hist_replicas): set (ri + i) % S, which holds byte
   // (ri + i) % 4 of the quality dword — byte i after a rotation by rot8 bits
-  uint32_t qcol[4];
+  uint32_t qcol[K][4];
   const uint32_t R = p.replicas;
   const uint32_t kset = ri % (4u * R);
   const uint32_t rot8 = 8u * (kset & 3u);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) qcol[i] = qhist_index(0u, ((kset + i) % (4u * R)) * CH + ch) * 4u;
-  constexpr uint32_t kHistBase = ADAPT ? (kFusedFilterWords + kCandWords) * 4u : 0u;   // == (char*)lds - LDS byte 0
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qcol[k][i] = qhist_index(0u, ((kset + i) % (4u * R)) * CH + lds_col(chk[k])) * 4u;
+  constexpr uint32_t kHistBase = ADAPT ? (kFusedFilterWords + kCandWordsT) * 4u : 0u;   // == (char*)lds - LDS byte 0
   uint32_t mask7;   // 127 << 7 in a VGPR (an SGPR or literal operand would put v_bitop3 in the slow class)
   asm("v_mov_b32 %0, 0x3f80" : "=v"(mask7));
   const uint32_t one_lo = 1u, one_hi = 65536u;
 
   // ADAPT: this wave's candidate queue (see kCandCap) and its fill (wave-uniform)
   uint2 *cand_q = reinterpret_cast<uint2 *>(lds_raw + kFusedFilterWords) + (tid >> 6) * kCandCap;
+  uint4 *cand_q16 = reinterpret_cast<uint4 *>(lds_raw + kFusedFilterWords) + (tid >> 6) * kCandCap;   // W16: 16-byte entries
   uint32_t cand_n = 0;
   uint32_t n_gt10 = 0;        // reads longer than 10 (kmers==NULL path, quack.c:215)
   uint32_t fixed_reads = 0;   // FIXED, tile 0: reads seen since the last flush
   uint32_t keep = 0;          // MODE 1 only
-  // SWAR byte counters for the 8 owned positions: [0] positions 0-3, [1] 4-7
-  uint32_t acc_v[2] = {0, 0}, acc_t[2] = {0, 0}, acc_c[2] = {0, 0}, acc_g[2] = {0, 0};
+  // SWAR byte counters for the 8 positions of a chunk: [0] positions 0-3, [1] 4-7 (W16: chunk k at [2k], [2k+1])
+  uint32_t acc_v[2 * K] = {}, acc_t[2 * K] = {}, acc_c[2 * K] = {}, acc_g[2 * K] = {};
   uint32_t since_spill = 0;
   // acc_t/c/g count the bytes that are NOT T/C/G (swar_ne, one instruction
   // shorter than the equality) and acc_v the events in which a byte was masked;
@@ -388,16 +420,18 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   // the end of the slice sit out under the exec mask and count their own
   // events (steps_v), and no per-event valid counter is needed at all.
   constexpr bool FAST_FIXED = FIXED && !SV;
-  uint32_t events = 0, steps_v = 0, fm0 = 0xFFFFFFFFu, fm1 = 0xFFFFFFFFu;
+  uint32_t events = 0, steps_v = 0, fm[2 * K];
+#pragma unroll
+  for (int d = 0; d < 2 * K; ++d) fm[d] = 0xFFFFFFFFu;
 
   auto spill = [&]() {
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < 2 * K; ++d) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const uint32_t off = (8u * ch + 4u * d + b) * 4u;
+        const uint32_t off = (8u * chk[d >> 1] + 4u * (d & 1) + b) * 4u;
         uint32_t v = events - ((acc_v[d] >> (8 * b)) & 0xFFu);   // acc_v counts the events in which the byte was masked
-        if (FAST_FIXED) v = (((d ? fm1 : fm0) >> (8 * b)) & 0xFFu) ? 0u : steps_v;
+        if (FAST_FIXED) v = ((fm[d] >> (8 * b)) & 0xFFu) ? 0u : steps_v;
         if (v == 0) continue;  // nothing valid => no T/C/G either
         lds_add(lds_base, off, v);
         uint32_t t = (acc_t[d] >> (8 * b)) & 0xFFu;
@@ -441,7 +475,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
         const uint32_t c8 = pp >> 3, j = pp & 7u;
         uint32_t c = 0;
         for (uint32_t rep = 0; rep < R; ++rep) {
-          const uint32_t w = lds[qhist_index(row, (rep * 4u + (j & 3u)) * CH + c8)];
+          const uint32_t w = lds[qhist_index(row, (rep * 4u + (j & 3u)) * CH + lds_col(c8))];
           c += (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
         }
         const uint32_t pos = P0 + pp;
@@ -498,7 +532,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
     const uint32_t P0 = tile * p.tile_pos;
     // first position of the owned chunk; halo lanes of tile 0 would sit before
     // the read and are parked beyond any read instead (they then never load)
-    const int32_t cpos_s = (int32_t)P0 + 8 * ch_signed;
+    const int32_t cpos_s = (int32_t)P0 + 8 * K * ch_signed;
     const uint32_t cpos = cpos_s < 0 ? 0xFFFFFF00u : (uint32_t)cpos_s;
     const bool sorted = !FIXED && p.order != nullptr;
     const uint64_t list_len = sorted ? p.reach[tile] : p.n_reads;   // reads this tile has to look at
@@ -538,10 +572,14 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
     const uint32_t off_limit = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
     const uint32_t cposp = cpos + (uint32_t)(slice_base & 3ull);
     if (FIXED) {
-      // the lane's chunk covers the same bytes of every read of the batch
-      const uint32_t nc = (lane_on && p.read_len > cpos) ? (p.read_len - cpos > 8u ? 8u : p.read_len - cpos) : 0u;
-      fm0 = nc >= 4u ? 0u : (0xFFFFFFFFu << (8u * nc));
-      fm1 = nc >= 8u ? 0u : (nc <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (nc - 4u))));
+      // the lane's chunks cover the same bytes of every read of the batch
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const uint32_t c0 = cpos + 8u * (uint32_t)k;
+        const uint32_t nc = (lane_on && p.read_len > c0) ? (p.read_len - c0 > 8u ? 8u : p.read_len - c0) : 0u;
+        fm[2 * k] = nc >= 4u ? 0u : (0xFFFFFFFFu << (8u * nc));
+        fm[2 * k + 1] = nc >= 8u ? 0u : (nc <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (nc - 4u))));
+      }
     }
 
     // Fixed-length batches: one pass over the slice, read r at r*L.  Ragged
@@ -649,7 +687,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
       uint32_t fixed_off0[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) fixed_off0[u] = FIXED ? ((uint32_t)u * RW + ri) * p.read_len + cposp : 0u;
-      auto issue = [&](uint32_t it, u32x3 (&q)[U], u32x3 (&s)[U], uint32_t (&nv)[U], uint32_t (&sk)[U],
+      auto issue = [&](uint32_t it, LoadT (&q)[U], LoadT (&s)[U], uint32_t (&nv)[U], uint32_t (&sk)[U],
                        uint32_t (&rl)[U]) __attribute__((always_inline)) {
         const uint32_t it_bytes = FIXED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)it) * p.read_len : 0u;
 #pragma unroll
@@ -666,17 +704,23 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             off = e.x + cpos;
             len = e.y;
           }
-          // bytes of this chunk inside the read; feeder lanes (ADAPT) load and
+          // bytes of this lane's chunk(s) inside the read; feeder lanes (ADAPT) load and
           // compute codes like their originals but count nothing
           uint32_t n_raw = (in_list && len > cpos) ? len - cpos : 0u;
-          n_raw = n_raw > 8u ? 8u : n_raw;
+          n_raw = n_raw > 8u * K ? 8u * K : n_raw;
           nv[u] = lane_on ? n_raw : 0u;
           // strided: the read's own length, in flight together with its bytes (consume turns it into n)
           if (SV) nv[u] = in_list ? p.lengths[(size_t)r_begin + rel] : 0u;
           off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
           sk[u] = AL ? 0u : (off & 3u);
-          off &= (AL && !FIXED) ? ~7u : ~3u;
-          if (AL && FIXED) {
+          off &= (AL && !FIXED) ? (W16 ? ~15u : ~7u) : ~3u;
+          if constexpr (W16) {
+            // two adjacent chunks, one dwordx4 per array (ragged: 16-byte aligned — the reads start on cache
+            // lines; fixed length: dword aligned).  Lanes past the end of their read fetch the slice's first line.
+            if (!FIXED) off = n_raw != 0 ? off : 0u;
+            q[u] = load16_aligned(qbase + off);
+            s[u] = load16_aligned(sbase + off);
+          } else if (AL && FIXED) {
             // read_len is a multiple of 4: every chunk starts on a dword
             q[u] = load8_aligned(qbase + off);
             s[u] = load8_aligned(sbase + off);
@@ -704,10 +748,27 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
       // Exact check of the queued candidates {plo, prev2 | hits << 2 | lane << 10 | rel << 16}, one entry per
       // lane.  Position and length of the chunk come back from the lane that queued it (ds_bpermute)
       // and from the read's descriptor: the queue never outlives its pass.
+      // W16: {own32, prev2 << 16 | prev16, hits16 | lane << 16, rel} — one entry per LANE, 16 windows.
       auto drain_candidates = [&]() {
+        constexpr uint32_t NW = 8u * K;                 // windows per entry
+        constexpr uint32_t kAll = (1u << NW) - 1u;
         for (uint32_t i = lane_id; i < ((cand_n + 63u) & ~63u); i += 64u) {   // whole waves: bpermute below
-          const uint2 e = cand_q[i < cand_n ? i : 0u];
-          const uint32_t src = (e.y >> 10) & 63u, rel = e.y >> 16;
+          uint32_t src, rel, hits, s_lo, s_hi;
+          if constexpr (W16) {
+            const uint4 e = cand_q16[i < cand_n ? i : 0u];
+            src = (e.z >> 16) & 63u;
+            rel = e.w;
+            hits = e.z & 0xFFFFu;
+            s_lo = e.x;
+            s_hi = e.y;
+          } else {
+            const uint2 e = cand_q[i < cand_n ? i : 0u];
+            src = (e.y >> 10) & 63u;
+            rel = e.y >> 16;
+            hits = (e.y >> 2) & 0xFFu;
+            s_lo = e.x;
+            s_hi = e.y & 3u;
+          }
           const uint32_t cp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)cpos);
           uint32_t len, rd;
           if (FIXED) {
@@ -717,18 +778,18 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             len = lds_list[rel].y;
             rd = lds_ridx[rel];
           }
-          uint32_t hits = i < cand_n ? (e.y >> 2) & 0xFFu : 0u;
+          hits = i < cand_n ? hits : 0u;
           // only windows that end inside the read, at e >= 9 (quack.c:206-213)
           const uint32_t n = len - cp;   // > 0: the lane counted something
-          hits &= n >= 8u ? 0xFFu : (1u << n) - 1u;
-          hits &= cp >= 9u ? 0xFFu : (0xFFu & ~((1u << (9u - cp)) - 1u));
-          const uint64_t stream = ((uint64_t)(e.y & 3u) << 32) | e.x;
+          hits &= n >= NW ? kAll : (1u << n) - 1u;
+          hits &= cp >= 9u ? kAll : (kAll & ~((1u << (9u - cp)) - 1u));
+          const uint64_t stream = ((uint64_t)s_hi << 32) | s_lo;
           uint32_t found = kNoHit;
           while (hits) {
             const uint32_t j = (uint32_t)__builtin_ctz(hits);
             hits &= hits - 1u;
-            // the window ending at owned position j = bits [2*(7-j), 2*(7-j)+20) of the (complemented) code stream
-            const uint32_t km = ((uint32_t)(stream >> (2u * (7u - j))) & kKmerMask) ^ kKmerMask;
+            // the window ending at owned position j = bits [2*(NW-1-j), 2*(NW-1-j)+20) of the (complemented) code stream
+            const uint32_t km = ((uint32_t)(stream >> (2u * (NW - 1u - j))) & kKmerMask) ^ kKmerMask;
             const bool in_table = p.bucket_log2 ? bucket_has(lds_buckets, km, p.bucket_mul, p.bucket_log2)
                                                 : ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) != 0;
             if (in_table) {
@@ -746,7 +807,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
         }
         cand_n = 0;
       };
-      auto consume = [&](const u32x3 (&q)[U], const u32x3 (&s)[U], const uint32_t (&nv)[U], const uint32_t (&sk)[U],
+      auto consume = [&](const LoadT (&q)[U], const LoadT (&s)[U], const uint32_t (&nv)[U], const uint32_t (&sk)[U],
                          const uint32_t (&rl)[U]) __attribute__((always_inline)) {
       // ADAPT builds run the U reads of a step in two rounds: first the letters of every
       // read (indicators, counters, codes, the four filter probes), then the quality
@@ -754,29 +815,43 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
       // issued ahead of the step's 8*U ds_adds and have long returned when they are
       // looked at (the kernel issues VALU work back to back on four waves per SIMD and
       // cannot afford to wait for an LDS round trip per read).
-      uint32_t qwU[U][2], ploU[U], prev16U[U], bytU[U][4], nU[U];
+      uint32_t qwU[U][K][2], ploU[U][K], bytU[U][K][4], nU[U];
       bool liveU[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // bytes past the end of the read -> 0xFF: quality row 127 is discarded
         // at flush time, and 0xFF & 31 matches none of T/C/G.
-        uint32_t n = nv[u];
+        uint32_t nl = nv[u];     // valid bytes of the lane's K chunks together
         if (SV) {   // nv[u] is the length of the read
-          n = (lane_on && nv[u] > cpos) ? nv[u] - cpos : 0u;
-          n = n > 8u ? 8u : n;
+          nl = (lane_on && nv[u] > cpos) ? nv[u] - cpos : 0u;
+          nl = nl > 8u ? 8u : nl;
         }
-        nU[u] = n;
+        nU[u] = nl;
         liveU[u] = true;
         // nothing of these reads reaches this tile (ragged batches, long
         // reads): the whole wave moves on.  ADAPT needs every lane's codes, but
         // then no lane has a valid window either.
-        if (!FIXED && __builtin_amdgcn_ballot_w64(n != 0) == 0) {
+        if (!FIXED && __builtin_amdgcn_ballot_w64(nl != 0) == 0) {
           liveU[u] = false;
           continue;
         }
-        if (FAST_FIXED && !ADAPT && n == 0) continue;   // per lane: past the end of the slice (its last step only)
-        const uint2 qa = AL ? make_uint2(q[u].x, q[u].y) : window8(q[u], sk[u]);
-        const uint2 sa = AL ? make_uint2(s[u].x, s[u].y) : window8(s[u], sk[u]);
+        if (FAST_FIXED && !ADAPT && nl == 0) continue;   // per lane: past the end of the slice (its last step only)
+        uint32_t own16K[K];
+        const bool count_me = !FAST_FIXED || nl != 0;   // ragged: every lane (masked bytes take care of themselves)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+        const uint32_t n = K == 1 ? nl : (nl > 8u * (uint32_t)k ? (nl - 8u * (uint32_t)k > 8u ? 8u : nl - 8u * (uint32_t)k) : 0u);
+        uint2 qa, sa;
+        if constexpr (W16) {
+          qa = k ? make_uint2(q[u].z, q[u].w) : make_uint2(q[u].x, q[u].y);
+          sa = k ? make_uint2(s[u].z, s[u].w) : make_uint2(s[u].x, s[u].y);
+        } else if constexpr (AL) {
+          qa = make_uint2(q[u].x, q[u].y);
+          sa = make_uint2(s[u].x, s[u].y);
+        } else {
+          qa = window8(q[u], sk[u]);
+          sa = window8(s[u], sk[u]);
+        }
         // Ragged: bytes past the end of the read -> 0xFF (quality row 127 is
         // discarded at flush time, 0xFF & 31 matches none of T/C/G).  Fixed
         // length: no masks at all — the bytes behind a read's last base belong
@@ -798,8 +873,8 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
           sw[0] |= m0;
           sw[1] |= m1;
           if (MODE == 0 || MODE == 3) {   // (every lane, also with n == 0: all of its bytes are masked in this event)
-            acc_v[0] += m0 & 0x01010101u;   // events in which the byte was masked
-            acc_v[1] += m1 & 0x01010101u;
+            acc_v[2 * k] += m0 & 0x01010101u;   // events in which the byte was masked
+            acc_v[2 * k + 1] += m1 & 0x01010101u;
           }
         }
         const uint32_t mk[2] = {m0, m1};
@@ -807,18 +882,17 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
           keep ^= qw[0] ^ qw[1] ^ sw[0] ^ sw[1];
           continue;
         }
-        const bool count_me = !FAST_FIXED || n != 0;   // ragged: every lane (masked bytes take care of themselves)
         if (ADAPT) {
-          qwU[u][0] = qw[0];
-          qwU[u][1] = qw[1];
+          qwU[u][k][0] = qw[0];
+          qwU[u][k][1] = qw[1];
         } else if ((MODE == 0 || MODE == 2) && count_me) {
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
             const uint32_t wr = __builtin_amdgcn_alignbit(qw[jj], qw[jj], rot8);
-            qhist_add<0, kHistBase>(wr, mask7, qcol[0], jj ? one_hi : one_lo);
-            qhist_add<1, kHistBase>(wr, mask7, qcol[1], jj ? one_hi : one_lo);
-            qhist_add<2, kHistBase>(wr, mask7, qcol[2], jj ? one_hi : one_lo);
-            qhist_add<3, kHistBase>(wr, mask7, qcol[3], jj ? one_hi : one_lo);
+            qhist_add<0, kHistBase>(wr, mask7, qcol[k][0], jj ? one_hi : one_lo);
+            qhist_add<1, kHistBase>(wr, mask7, qcol[k][1], jj ? one_hi : one_lo);
+            qhist_add<2, kHistBase>(wr, mask7, qcol[k][2], jj ? one_hi : one_lo);
+            qhist_add<3, kHistBase>(wr, mask7, qcol[k][3], jj ? one_hi : one_lo);
           }
         }
         if (MODE == 0 || MODE == 3) {
@@ -839,13 +913,11 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
               const uint32_t inv01 = (ADAPT && !FAST_FIXED) ? (mk[d] & 0x01010101u) : 0u;
-              acc_t[d] += nt[d] | inv01;
-              acc_c[d] += nc[d] | inv01;
-              acc_g[d] += ng[d] | inv01;
+              acc_t[2 * k + d] += nt[d] | inv01;
+              acc_c[2 * k + d] += nc[d] | inv01;
+              acc_g[2 * k + d] += ng[d] | inv01;
             }
-            if (FAST_FIXED) steps_v += 1u;
           }
-          if (!FAST_FIXED) events += 1u;
           if (ADAPT) {
             // COMPLEMENTED 2-bit codes (A and everything else 3, T 2, C 1, G 0) of the 8
             // owned bases, first base most significant.  The code is LINEAR in the
@@ -854,19 +926,30 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             // shifts, no multiplies (v_mul_lo_u32 is quarter rate).
             constexpr uint32_t kW1 = 0x01041040u, kW2 = 0x02082080u, kW3 = 0x030C30C0u, kBias = 0u - 255u;
             const uint32_t c80 = __builtin_amdgcn_udot4(ng[0], kW3, __builtin_amdgcn_udot4(nc[0], kW2, __builtin_amdgcn_udot4(nt[0], kW1, kBias, false), false), false);
-            const uint32_t own16 = __builtin_amdgcn_udot4(ng[1], kW3, __builtin_amdgcn_udot4(nc[1], kW2, __builtin_amdgcn_udot4(nt[1], kW1, (c80 << 8) + kBias, false), false), false);
-            const uint32_t prev16 = from_prev_lane(own16);   // positions cpos-8 .. cpos-1
-            const uint32_t plo = (prev16 << 16) | own16;
-            prev16U[u] = prev16;
-            ploU[u] = plo;
-            // The 9-mer that ends at owned position j is bits [2*(7-j), 2*(7-j)+18)
-            // of plo.  It is the suffix of the window ending at j and the prefix of
-            // the window ending at j+1, and every window has exactly one such 9-mer
-            // ending on an even position: the four probes j = 0,2,4,6 cover the
-            // lane's eight windows.  (The filter holds both 9-mers of every adapter
-            // 10-mer; it sits at LDS byte 0, so the key field is the address.)
+            own16K[k] = __builtin_amdgcn_udot4(ng[1], kW3, __builtin_amdgcn_udot4(nc[1], kW2, __builtin_amdgcn_udot4(nt[1], kW1, (c80 << 8) + kBias, false), false), false);
+          }
+        }
+        }   // k
+        if (MODE == 0 || MODE == 3) {
+          if (FAST_FIXED && count_me) steps_v += 1u;
+          if (!FAST_FIXED) events += 1u;
+          if (ADAPT) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) bytU[u][m] = lds_abs_u8(__builtin_amdgcn_ubfe(plo, 2 * (7 - 2 * m) + 3, kFusedFilterLog2 - 3));
+            for (int k = 0; k < K; ++k) {
+              // the 8 positions in front of the chunk: the previous lane's last chunk (DPP), or this lane's own
+              // chunk before it
+              const uint32_t prev16 = k == 0 ? from_prev_lane(own16K[K - 1]) : own16K[k - 1];
+              const uint32_t plo = (prev16 << 16) | own16K[k];
+              ploU[u][k] = plo;
+              // The 9-mer that ends at owned position j is bits [2*(7-j), 2*(7-j)+18)
+              // of plo.  It is the suffix of the window ending at j and the prefix of
+              // the window ending at j+1, and every window has exactly one such 9-mer
+              // ending on an even position: the four probes j = 0,2,4,6 cover the
+              // chunk's eight windows.  (The filter holds both 9-mers of every adapter
+              // 10-mer; it sits at LDS byte 0, so the key field is the address.)
+#pragma unroll
+              for (int m = 0; m < 4; ++m) bytU[u][k][m] = lds_abs_u8(__builtin_amdgcn_ubfe(plo, 2 * (7 - 2 * m) + 3, kFusedFilterLog2 - 3));
+            }
           }
         }
             }
@@ -874,13 +957,12 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (!liveU[u]) continue;   // (wave-uniform)
-          const uint32_t n = nU[u];
-          if (!FAST_FIXED || n != 0) {
+          if (!FAST_FIXED || nU[u] != 0) {
 #ifdef QK_DUMMY_VALU   // sensitivity probe (tools only): N extra VALU instructions per chunk
 #pragma unroll
             for (int q = 0; q < QK_DUMMY_VALU; ++q) {
 #if QK_DUMMY_SLOW == 2   // an LDS atomic on quality row 0 (never flushed), same bank pattern as the real ones
-              asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(qcol[q & 3]), "v"(one_lo), "i"(kHistBase) : "memory");
+              asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(qcol[0][q & 3]), "v"(one_lo), "i"(kHistBase) : "memory");
 #elif QK_DUMMY_SLOW
               asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(keep));
 #else
@@ -889,33 +971,45 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             }
 #endif
 #pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-              const uint32_t wr = __builtin_amdgcn_alignbit(qwU[u][jj], qwU[u][jj], rot8);
-              qhist_add<0, kHistBase>(wr, mask7, qcol[0], jj ? one_hi : one_lo);
-              qhist_add<1, kHistBase>(wr, mask7, qcol[1], jj ? one_hi : one_lo);
-              qhist_add<2, kHistBase>(wr, mask7, qcol[2], jj ? one_hi : one_lo);
-              qhist_add<3, kHistBase>(wr, mask7, qcol[3], jj ? one_hi : one_lo);
+              const uint32_t wr = __builtin_amdgcn_alignbit(qwU[u][k][jj], qwU[u][k][jj], rot8);
+              qhist_add<0, kHistBase>(wr, mask7, qcol[k][0], jj ? one_hi : one_lo);
+              qhist_add<1, kHistBase>(wr, mask7, qcol[k][1], jj ? one_hi : one_lo);
+              qhist_add<2, kHistBase>(wr, mask7, qcol[k][2], jj ? one_hi : one_lo);
+              qhist_add<3, kHistBase>(wr, mask7, qcol[k][3], jj ? one_hi : one_lo);
             }
           }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (!liveU[u]) continue;
-          const uint32_t n = nU[u], plo = ploU[u];
-          uint32_t t9[4];
+          const uint32_t n = nU[u];
+          uint32_t hits = 0;
 #pragma unroll
-          for (int m = 0; m < 4; ++m)   // 0 or ~0
-            t9[m] = (uint32_t)__builtin_amdgcn_sbfe((int)bytU[u][m], __builtin_amdgcn_ubfe(plo, 2 * (7 - 2 * m), 3), 1);
-          // windows j (suffix) and j+1 (prefix) of every 9-mer that passed; lanes that
-          // count nothing (feeders, halo, past the end) have no windows
-          uint32_t hits = (t9[0] & 0x03u) | (t9[1] & 0x0Cu) | (t9[2] & 0x30u) | (t9[3] & 0xC0u);
+          for (int k = 0; k < K; ++k) {
+            const uint32_t plo = ploU[u][k];
+            uint32_t t9[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)   // 0 or ~0
+              t9[m] = (uint32_t)__builtin_amdgcn_sbfe((int)bytU[u][k][m], __builtin_amdgcn_ubfe(plo, 2 * (7 - 2 * m), 3), 1);
+            // windows j (suffix) and j+1 (prefix) of every 9-mer that passed
+            const uint32_t h8 = (t9[0] & 0x03u) | (t9[1] & 0x0Cu) | (t9[2] & 0x30u) | (t9[3] & 0xC0u);
+            hits |= h8 << (8 * k);
+          }
+          // lanes that count nothing (feeders, halo, past the end) have no windows
           hits = n ? hits : 0u;
           const uint64_t pushers = __builtin_amdgcn_ballot_w64(hits != 0u);
           if (pushers) {   // (wave-uniform)
-            const uint32_t prev2 = from_prev_lane(prev16U[u]) & 3u;   // position cpos-9
+            // position cpos-9: the last base of the chunk two chunks back — the previous lane's (W16: its first chunk)
+            const uint32_t prev2 = from_prev_lane(W16 ? ploU[u][0] : (ploU[u][0] >> 16)) & 3u;
             if (hits) {
               const uint32_t at = cand_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushers, 0u));
-              cand_q[at] = make_uint2(plo, prev2 | (hits << 2) | lane10 | (rl[u] << 16));
+              if constexpr (W16)
+                cand_q16[at] = make_uint4((ploU[u][0] << 16) | (ploU[u][1] & 0xFFFFu), (prev2 << 16) | (ploU[u][0] >> 16), hits | (lane_id << 16), rl[u]);
+              else
+                cand_q[at] = make_uint2(ploU[u][0], prev2 | (hits << 2) | lane10 | (rl[u] << 16));
             }
             cand_n += (uint32_t)__builtin_popcountll(pushers);
             if (cand_n > kCandCap - 64u) drain_candidates();
@@ -930,7 +1024,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
       if constexpr (PD > 1) {
         // PD register sets: the loads of the next PD-1 steps are in flight
         // while one step is consumed
-        u32x3 q[PD][U], s[PD][U];
+        LoadT q[PD][U], s[PD][U];
         uint32_t nv[PD][U], sk[PD][U], rl[PD][U];
 #pragma unroll
         for (int d = 0; d < PD - 1; ++d) issue((uint32_t)d * RW * U, q[d], s[d], nv[d], sk[d], rl[d]);
@@ -945,7 +1039,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
       } else {
         if (STAGED) load_desc(0u);
         for (uint32_t it = 0; it < n_list; it += RW * U) {
-          u32x3 q[U], s[U];
+          LoadT q[U], s[U];
           uint32_t nv[U], sk[U], rl[U];
           issue(it, q, s, nv, sk, rl);
           if (STAGED) load_desc(it + RW * U);

@@ -184,6 +184,7 @@ struct Plan {
   uint64_t reads_per_slice, n_slices, n_blocks;
   uint32_t bucket_log2, halo, replicas;
   bool fused_adapters, dynamic, aligned, sorted;
+  bool w16;   // 16 positions per lane (qk::hist_kernel<..., W16>): dword-aligned batches under the planner's own geometry
 };
 constexpr unsigned kQueueRing = 8;       // queue sets that rotate (launches of one accumulator run in order)
 constexpr unsigned kQueueTiles = 1u << 17;  // counters per launch: reads of up to 64 Mbases (512-position tiles)
@@ -208,9 +209,14 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   const bool want_pipe = a->pipe > 0 ? a->pipe > 1 : (a->unroll <= 0 && !ragged && T == 1024);
   pl->pipe = a->pipe > 0 ? a->pipe : (want_pipe ? 2 : 1);
   pl->unroll = a->unroll > 0 ? a->unroll : ((want_pipe && !ragged) ? (pl->fused_adapters ? 2 : 1) : 4);
+  // 16 positions per lane (W16): every batch form whose chunks are dword aligned — reads on cache lines in several
+  // tiles, fixed-length reads of a multiple of 4 bases — under the planner's own geometry
+  const bool tuned = a->unroll || a->pipe || T != 1024;
+  bool w16 = !tuned && !strided && !getenv("QUACK_HIP_NO_W16") &&
+             (ragged ? aligned : ((max_len & 3u) == 0 && base_aligned4 && !getenv("QUACK_HIP_NO_ALIGN4")));
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
   uint32_t single_cap = 576u;
-  while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, qk::hist_replicas(single_cap / 8), a->adapters, 0, ragged) > 160 * 1024)
+  while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, qk::hist_replicas(single_cap / 8), a->adapters, 0, ragged, qk::kStageReads, w16) > 160 * 1024)
     single_cap -= 32u;
   uint32_t cap = a->tile > 0 ? std::max<uint32_t>(8, (uint32_t)a->tile / 8 * 8) : single_cap;
   cap = std::min(cap, single_cap);
@@ -219,9 +225,9 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
     cap = 512;
     n_tiles = (max_len + cap - 1) / cap;
   }
-  const uint32_t lanes = pl->fused_adapters ? T / 64 * 62 : T;   // two feeder lanes per wave when fused
-  if (cap / 8 + 2 > lanes) {
-    cap = (lanes - 2) * 8;
+  const uint32_t lanes8 = pl->fused_adapters ? T / 64 * 62 : T;   // two feeder lanes per wave when fused
+  if (cap / 8 + 2 > lanes8) {
+    cap = (lanes8 - 2) * 8;
     n_tiles = (max_len + cap - 1) / cap;
   }
   uint32_t tile_pos = (uint32_t)round_up((max_len + n_tiles - 1) / n_tiles, 8);
@@ -243,17 +249,30 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
       pl->pipe = 2;
     }
   }
+  if (ragged && !pl->aligned) w16 = false;   // (a packed batch, or one tile: 12-byte windows)
   // fixed-length reads of a multiple of 4 bases: every chunk is dword aligned
   // (the batch base is: hipMalloc / pinned slots; submit_device checks it)
   if (!ragged && (max_len & 3u) == 0 && base_aligned4 && T == 1024 && !a->unroll && !a->pipe &&
       !getenv("QUACK_HIP_NO_ALIGN4"))
     pl->aligned = true;
   if (pl->aligned && !ragged && pl->fused_adapters) pl->pipe = env_int("QUACK_HIP_ADAPT_PD", pl->pipe), pl->unroll = env_int("QUACK_HIP_ADAPT_U", pl->unroll);
+  if (!pl->aligned || (pl->fused_adapters && (getenv("QUACK_HIP_ADAPT_PD") || getenv("QUACK_HIP_ADAPT_U")))) w16 = false;
+  if (w16) {
+    // a lane owns two adjacent chunks: tiles of whole chunk pairs (fixed-length reads: the columns behind the
+    // read hold the next read's bytes and are never flushed, as before), one read per lane and step with the
+    // next step's loads in flight — the same bytes in flight as two reads of 8 positions
+    tile_pos = (uint32_t)round_up(tile_pos, 16);
+    pl->unroll = env_int("QUACK_HIP_W16_U", 1);
+    pl->pipe = env_int("QUACK_HIP_W16_PD", 2);
+  }
+  pl->w16 = w16;
   pl->n_tiles = n_tiles;
   pl->tile_pos = tile_pos;
   pl->ch = tile_pos / 8;
-  pl->halo = (pl->fused_adapters && n_tiles > 1) ? 2u : 0u;   // lanes covering the 16 positions before a tile
-  pl->rw = (pl->fused_adapters ? T / 64 * 62 : T) / (pl->ch + pl->halo);
+  // lanes covering the 16 positions before a tile: two chunks of 8 (W16: one lane)
+  pl->halo = (pl->fused_adapters && n_tiles > 1) ? (w16 ? 1u : 2u) : 0u;
+  // lanes per workgroup that own chunks (fused: two feeder lanes per wave, W16 one) / lanes per read row
+  pl->rw = (pl->fused_adapters ? T / 64 * (w16 ? 63 : 62) : T) / (pl->ch / (w16 ? 2 : 1) + pl->halo);
   // replicas of the quality counters (bank balance, see qk::hist_replicas)
   pl->replicas = qk::hist_replicas(pl->ch);
   if (const int r = env_int("QUACK_HIP_REPLICAS", 0)) pl->replicas = std::min<uint32_t>((uint32_t)r, pl->replicas);
@@ -262,9 +281,9 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // the queued candidates are checked against the global table)
   pl->bucket_log2 = pl->fused_adapters ? a->bucket_log2 : 0;
   // (the exact table matters more than the last replica)
-  while (pl->bucket_log2 && pl->replicas > 1 && qk::hist_lds_bytes(pl->ch, pl->replicas, true, pl->bucket_log2, ragged) > 160 * 1024)
+  while (pl->bucket_log2 && pl->replicas > 1 && qk::hist_lds_bytes(pl->ch, pl->replicas, true, pl->bucket_log2, ragged, qk::kStageReads, w16) > 160 * 1024)
     --pl->replicas;
-  if (pl->bucket_log2 && qk::hist_lds_bytes(pl->ch, pl->replicas, true, pl->bucket_log2, ragged) > 160 * 1024) pl->bucket_log2 = 0;
+  if (pl->bucket_log2 && qk::hist_lds_bytes(pl->ch, pl->replicas, true, pl->bucket_log2, ragged, qk::kStageReads, w16) > 160 * 1024) pl->bucket_log2 = 0;
   // ragged: reads staged per pass.  A pass should hold many steps (36 bp reads: 816 per
   // step, so passes of 1024 staged every 1.25 steps: 1.10 ms per 40M reads, 0.5x the fixed
   // path), as far as the LDS next to the histogram allows
@@ -272,10 +291,10 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   if (ragged) {
     const uint64_t want = step * 12;
     while (pl->stage_reads < qk::kStageReadsMax && pl->stage_reads < want &&
-           qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, true, pl->stage_reads * 2) <= 160 * 1024)
+           qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, true, pl->stage_reads * 2, w16) <= 160 * 1024)
       pl->stage_reads *= 2;
   }
-  size_t lds = qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, ragged, pl->stage_reads);
+  size_t lds = qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, ragged, pl->stage_reads, w16);
   if (lds > 160 * 1024) return fail(QK_EINVAL, "LDS tile too large (%zu bytes)", lds);
   // residency: the kernels need 89-104 VGPRs, i.e. 4 waves per SIMD = 1024
   // threads per CU, and the LDS image must fit as many times
@@ -331,9 +350,19 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
 }
 
 template <int T, int U, int PD>
-int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, bool aligned, bool strided, dim3 grid,
+int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, bool aligned, bool strided, bool w16, dim3 grid,
                    size_t lds, hipStream_t st) {
   void (*k)(const qk::HistParams) = nullptr;
+  if (w16) {
+    // 16 positions per lane: built for the step shapes the planner (or QUACK_HIP_W16_U / _PD) asks for
+    if (aligned && mode == 0 && !strided) {
+      if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 2)) {
+        if (fixed) k = adapt ? qk::hist_kernel<T, U, true, 0, true, PD, true, false, true> : qk::hist_kernel<T, U, true, 0, false, PD, true, false, true>;
+        else k = adapt ? qk::hist_kernel<T, U, false, 0, true, PD, true, false, true> : qk::hist_kernel<T, U, false, 0, false, PD, true, false, true>;
+      }
+    }
+    if (!k) return fail(QK_EINVAL, "the 16-positions-per-lane kernel is not built for unroll %d / pipe %d", U, PD);
+  } else
   if (strided) {
     // fixed stride + per-read lengths: built for the planner's own choice only
     if (fixed && aligned && mode == 0) {
@@ -355,7 +384,7 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
       if (!adapt) k = qk::hist_kernel<T, U, false, 0, false, PD, true>;
 #endif
   }
-  if (!strided && aligned && fixed && mode == 0) {
+  if (!w16 && !strided && aligned && fixed && mode == 0) {
     if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 2))
       k = adapt ? qk::hist_kernel<T, U, true, 0, true, PD, true> : qk::hist_kernel<T, U, true, 0, false, PD, true>;
     if constexpr (T == 1024 && PD > 2)
@@ -415,10 +444,10 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
 
 int launch_hist(qk_accum *a, const qk::HistParams &hp, const Plan &pl, bool fixed, int mode, bool adapt,
                 hipStream_t st, bool strided = false) {
-  const size_t lds = qk::hist_lds_bytes(hp.ch, pl.replicas, adapt, hp.bucket_log2, !fixed, pl.stage_reads);
+  const size_t lds = qk::hist_lds_bytes(hp.ch, pl.replicas, adapt, hp.bucket_log2, !fixed, pl.stage_reads, pl.w16);
   dim3 grid((unsigned)pl.n_blocks);
 #define QK_TU(TT, UU, PP) \
-  if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, strided, grid, lds, st);
+  if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, strided, pl.w16, grid, lds, st);
   QK_TU(1024, 4, 1) QK_TU(1024, 2, 1) QK_TU(1024, 1, 1)
   QK_TU(1024, 4, 2) QK_TU(1024, 2, 2) QK_TU(1024, 1, 2)
   QK_TU(1024, 2, 3) QK_TU(1024, 2, 4) QK_TU(1024, 1, 4)
@@ -839,8 +868,8 @@ int qk_debug_plan(uint64_t n_reads, uint32_t max_len, int ragged, int adapters, 
   if (rc) return rc;
   out[0] = pl.n_tiles; out[1] = pl.tile_pos; out[2] = pl.ch; out[3] = pl.rw;
   out[4] = (uint64_t)pl.unroll; out[5] = (uint64_t)pl.pipe; out[6] = pl.reads_per_slice; out[7] = pl.n_slices;
-  out[8] = pl.n_blocks; out[9] = qk::hist_lds_bytes(pl.ch, pl.replicas, pl.fused_adapters, pl.bucket_log2, ragged != 0, pl.stage_reads);
-  out[10] = pl.halo; out[11] = pl.fused_adapters; out[12] = pl.dynamic; out[13] = pl.aligned;
+  out[8] = pl.n_blocks; out[9] = qk::hist_lds_bytes(pl.ch, pl.replicas, pl.fused_adapters, pl.bucket_log2, ragged != 0, pl.stage_reads, pl.w16);
+  out[10] = pl.halo; out[11] = pl.fused_adapters; out[12] = pl.dynamic; out[13] = (pl.aligned ? 1u : 0u) | (pl.w16 ? 2u : 0u);
   out[14] = pl.replicas; out[15] = qk::hist_row_dwords(pl.ch, pl.replicas);
   return QK_OK;
 }

@@ -36,8 +36,11 @@ def test_plans_fit_the_hardware(ragged, adapters):
         assert p["lds"] <= 160 * 1024, ctx                                  # one workgroup's LDS
         assert p["tile_pos"] == 8 * p["ch"] and p["n_tiles"] * p["tile_pos"] >= max_len, ctx
         assert (p["n_tiles"] - 1) * p["tile_pos"] < max_len, ctx            # no empty tile
-        lanes = 1024 // 64 * 62 if p["fused"] else 1024
-        assert p["rw"] >= 1 and p["rw"] * (p["ch"] + p["halo"]) <= lanes, ctx
+        w16 = bool(p["aligned"] & 2)          # 16 positions per lane: a lane owns two adjacent chunks
+        lanes = 1024 // 64 * (63 if w16 else 62) if p["fused"] else 1024
+        assert not w16 or (p["ch"] % 2 == 0 and p["aligned"] & 1), ctx
+        assert p["rw"] >= 1 and p["rw"] * (p["ch"] // (2 if w16 else 1) + p["halo"]) <= lanes, ctx
+        assert p["halo"] == ((1 if w16 else 2) if p["fused"] and p["n_tiles"] > 1 else 0), ctx
         step = p["rw"] * p["unroll"]
         assert p["reads_per_slice"] % step == 0 and p["reads_per_slice"] + step <= 65535, ctx   # u16 LDS counters
         assert p["n_slices"] * p["reads_per_slice"] >= n_reads, ctx          # every read belongs to a slice
@@ -45,16 +48,17 @@ def test_plans_fit_the_hardware(ragged, adapters):
         assert p["row_dwords"] % 32 == 0 and p["row_dwords"] >= 4 * p["replicas"] * p["ch"], ctx  # bank == column
         assert p["dynamic"] == (p["n_tiles"] > 1), ctx
         assert p["n_blocks"] >= 1 and (p["dynamic"] or p["n_blocks"] == p["n_slices"]), ctx
-        assert (p["unroll"], p["pipe"]) == ((4, 1) if ragged else ((2, 2) if adapters else (1, 2))), ctx
-        # fixed-length reads of a multiple of 4 bases take the dword-aligned variant (one dwordx2 per chunk)
-        assert p["aligned"] == (not ragged and max_len % 4 == 0), ctx
+        assert (p["unroll"], p["pipe"]) == ((4, 1) if ragged else ((1, 2) if w16 else ((2, 2) if adapters else (1, 2)))), ctx
+        # fixed-length reads of a multiple of 4 bases take the dword-aligned variant, 16 positions per lane
+        assert p["aligned"] == (3 if (not ragged and max_len % 4 == 0) else 0), ctx
 
 
 def test_cache_line_plans():
     for max_len in (600, 1000, 5000, 20000, 100000):
         for adapters in (False, True):
             p = plan(100000, max_len, ragged=True, adapters=adapters, gapped=True, aligned=True)
-            assert p["aligned"] and p["tile_pos"] % 128 == 0 and p["n_tiles"] > 1 and p["lds"] <= 160 * 1024, (max_len, p)
+            assert p["aligned"] == 3 and p["tile_pos"] % 128 == 0 and p["n_tiles"] > 1 and p["lds"] <= 160 * 1024, (max_len, p)
+            assert (p["unroll"], p["pipe"]) == (1, 2) and p["rw"] * (p["ch"] // 2 + p["halo"]) <= (1008 if adapters else 1024), (max_len, p)
     p = plan(100000, 150, ragged=True, gapped=True, aligned=True)       # one tile: nothing to align
     assert not p["aligned"] and p["n_tiles"] == 1
     with pytest.raises(RuntimeError):
