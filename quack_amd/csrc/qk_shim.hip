@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -48,6 +49,23 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 uint64_t round_up(uint64_t v, uint64_t m) { return (v + m - 1) / m * m; }
+
+// QUACK_VERBOSE: where the start-up of an accumulator goes (stderr), the question behind every end-to-end number
+struct Lap {
+  const bool on = getenv("QUACK_VERBOSE") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  char line[512] = "";
+  void mark(const char *what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    const size_t l = strlen(line);
+    snprintf(line + l, sizeof line - l, " %s %.1f ms,", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+  void print(const char *head) {
+    if (on) fprintf(stderr, "[quack] %s:%s\n", head, line);
+  }
+};
 
 int env_int(const char *name, int dflt) {
   const char *s = getenv(name);
@@ -138,10 +156,12 @@ int ensure_slot(qk_accum *a, int i) {
     if (const int kb = env_int("QUACK_HIP_BATCH_KB", 0)) a->cap_bytes = (uint64_t)kb << 10;   // (tests: tiny slots)
     a->cap_reads = a->cap_bytes / 32 + 1024;  // >= one read per 32 bytes
   }
+  Lap lap;
   QK_HIP(hipHostMalloc((void **)&s.h_seq, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
   QK_HIP(hipHostMalloc((void **)&s.h_qual, a->cap_bytes + QK_TAIL_SLACK, hipHostMallocDefault));
   QK_HIP(hipHostMalloc((void **)&s.h_off, (a->cap_reads + 1) * sizeof(uint64_t), hipHostMallocDefault));
   QK_HIP(hipHostMalloc((void **)&s.h_len, a->cap_reads * sizeof(uint32_t), hipHostMallocDefault));
+  lap.mark("pinned");
   QK_HIP(hipMalloc((void **)&s.d_len, a->cap_reads * sizeof(uint32_t)));
   QK_HIP(hipMalloc((void **)&s.d_seq, a->cap_bytes + QK_TAIL_SLACK));
   QK_HIP(hipMalloc((void **)&s.d_qual, a->cap_bytes + QK_TAIL_SLACK));
@@ -149,8 +169,11 @@ int ensure_slot(qk_accum *a, int i) {
   if (a->adapters) QK_HIP(hipMalloc((void **)&s.d_hit, a->cap_reads * sizeof(uint32_t)));
   QK_HIP(hipMemset(s.d_seq + a->cap_bytes, 0, QK_TAIL_SLACK));
   QK_HIP(hipMemset(s.d_qual + a->cap_bytes, 0, QK_TAIL_SLACK));
+  lap.mark("device");
   QK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
   QK_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  lap.mark("stream");
+  lap.print(i ? "slot 1" : "slot 0");
   return QK_OK;
 }
 
@@ -212,8 +235,15 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // 16 positions per lane (W16): every batch form whose chunks are dword aligned — reads on cache lines in several
   // tiles, fixed-length reads of a multiple of 4 bases — under the planner's own geometry
   const bool tuned = a->unroll || a->pipe || T != 1024;
+  // (measured, round 3, same box: 10M x 300 + adapters 1.385 -> 1.27-1.29 ms, 1-20 kb reads on cache lines 0.575 -> 0.56;
+  // fixed-length reads WITHOUT the adapter scan are memory-bound with 8 positions per lane at 70 VGPRs and lose 2-9 %
+  // with 16 at 107 — 100 bp 0.341 -> 0.354 ms, 36 bp 0.140 -> 0.154 —, so they keep one chunk per lane)
   bool w16 = !tuned && !strided && !getenv("QUACK_HIP_NO_W16") &&
-             (ragged ? aligned : ((max_len & 3u) == 0 && base_aligned4 && !getenv("QUACK_HIP_NO_ALIGN4")));
+             (ragged ? aligned : (pl->fused_adapters && (max_len & 3u) == 0 && base_aligned4 && !getenv("QUACK_HIP_NO_ALIGN4") &&
+                                  // short reads whose last pair would be half empty lose more lanes than the pairs save
+                                  // (36 bp: 48 columns for 36 positions, 0.236 -> 0.251 ms; 76 bp 0.417 -> 0.383, 100 bp 0.521 -> 0.497)
+                                  (max_len >= 64 || round_up(max_len, 16) == round_up(max_len, 8))));
+  if (getenv("QUACK_HIP_W16_ALWAYS") && !tuned && !strided && !ragged && (max_len & 3u) == 0 && base_aligned4) w16 = true;   // (tests: the plain fixed-length variant)
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
   uint32_t single_cap = 576u;
   while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, qk::hist_replicas(single_cap / 8), a->adapters, 0, ragged, qk::kStageReads, w16) > 160 * 1024)
@@ -437,8 +467,15 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
       done.insert({(const void *)k, dev});
     }
   }
+  static bool first_launch = true;   // (QUACK_VERBOSE: the first launch of the process loads the code object)
+  Lap lap;
   hipLaunchKernelGGL(k, grid, dim3(T), lds, st, hp);
   QK_HIP(hipGetLastError());
+  if (first_launch && lap.on) {
+    first_launch = false;
+    lap.mark("enqueue");
+    lap.print("first histogram launch");
+  }
   return QK_OK;
 }
 
@@ -879,12 +916,14 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
   if (!out) return fail(QK_EINVAL, "out is NULL");
   *out = nullptr;
   int n = 0;
+  Lap lap;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return fail(QK_ENODEV, "no HIP device available (the accumulation path has no CPU fallback)");
   if (device < 0 || device >= n) return fail(QK_EINVAL, "device %d out of range (0..%d)", device, n - 1);
   qk_accum *a = new (std::nothrow) qk_accum();
   if (!a) return fail(QK_ENOMEM, "out of memory");
   a->device = device;
+  lap.mark("runtime");
   int rc = QK_OK;
   do {
     if ((rc = set_device(a))) break;
@@ -899,11 +938,13 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
     a->pipe = env_int("QUACK_HIP_PIPE", a->pipe);
     a->tile = env_int("QUACK_HIP_TILE", a->tile);
     a->wgs_per_cu = env_int("QUACK_HIP_WGS_PER_CU", a->wgs_per_cu);
+    lap.mark("device");
     if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&a->order_ev, hipEventDisableTiming) != hipSuccess) {
       rc = fail(QK_EHIP, "hipStreamCreate / hipEventCreate failed");
       break;
     }
+    lap.mark("stream");
     if (kmer_bitset) {
       a->adapters = true;
       rc = qk::upload_kmer_tables(kmer_bitset, &a->d_kmer_bits, &a->d_kmer_filter, &a->filter_bits);
@@ -928,8 +969,11 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
       rc = fail(QK_EHIP, "hipMalloc failed");
       break;
     }
+    lap.mark("tables");
     if ((rc = grow_table(a, std::max<uint64_t>(max_len_hint, 64)))) break;
+    lap.mark("counters");
   } while (0);
+  lap.print("qk_accum_create");
   if (rc) {
     qk_accum_destroy(a);
     return rc;

@@ -127,6 +127,12 @@ int qkh_main(int argc, char **argv) {
     }
   }
   n_devs = qkh_device_list(devs, 64);
+  if (getenv("QUACK_INIT_FIRST")) {   /* experiment: the HIP runtime comes up before the decoder threads exist */
+    int n = 0;
+    const double t = now_s();
+    (void)qk_device_count(&n);
+    if (getenv("QUACK_VERBOSE")) fprintf(stderr, "[quack] main: HIP runtime up in %.3f s (alone)\n", now_s() - t);
+  }
 
   /* accumulate first (quack.c:911,917), print afterwards */
   {

@@ -71,6 +71,56 @@ def test_adapters_fixed(L):
     assert ob.accumulate_batch(seq, qual, read_len=L, kmers=k)[0][:, 96].sum() > 100  # hits happened
 
 
+@pytest.mark.parametrize("adapters", [False, True], ids=["plain", "adapters"])
+def test_sixteen_positions_per_lane_every_shape(adapters, monkeypatch):
+    monkeypatch.setenv("QUACK_HIP_W16_ALWAYS", "1")      # (the planner picks it by itself only with the adapter scan)
+    """fixed-length reads of a multiple of 4 bases run with 16 positions per lane (hist_kernel W16: two adjacent
+    chunks per lane, one dwordx4 per array, odd chunk counts rounded up to whole pairs, one feeder lane per wave,
+    one halo lane in front of a tile, per-lane candidate entries of 16 windows): every read length 4..128, lengths
+    around the one-tile limit with and without the adapter tables, two and more tiles, adapters at every offset of
+    a lane's 16 positions; and the same reads with 8 positions per lane (QUACK_HIP_NO_W16) must agree too"""
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads) if adapters else None
+    bits = ob.kmers_to_bitset(k) if adapters else None
+    rng = np.random.default_rng(16)
+    for L in list(range(4, 132, 4)) + [148, 152, 156, 160, 296, 300, 304, 308, 444, 448, 452, 572, 576, 580, 600, 1024, 1500]:
+        n = 1500 if L <= 160 else 400
+        seq, qual = synth.fixed(n, L, seed=L, q_lo=0, q_hi=60)
+        seq = seq.copy().reshape(n, L)
+        if adapters and L >= 14:
+            for r in range(0, n, 3):                     # an adapter at a sweep of offsets (every position of a lane's 16)
+                ad = np.frombuffer(ads[r % len(ads)], np.uint8)
+                at = (r // 3) % max(1, L - 10)
+                m = min(len(ad), L - at)
+                seq[r, at:at + m] = ad[:m]
+        seq = seq.reshape(-1)
+        want = ob.accumulate_batch(seq, qual, read_len=L, kmers=k)
+        assert_same(hip_table(seq, qual, read_len=L, kmers_bits=bits, chunks=1 + L % 3), want)
+    assert not adapters or want[0][:, 96].sum() > 0
+
+
+def test_sixteen_positions_per_lane_on_and_off(monkeypatch):
+    import torch
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    bits = ob.kmers_to_bitset(k)
+    seq, qual = synth.fixed(30000, 300, seed=5)
+    seq = synth.splice_adapters(seq, 300, ads, seed=6)
+    want = ob.accumulate_batch(seq, qual, read_len=300, kmers=k)
+    for env in ({}, {"QUACK_HIP_NO_W16": "1"}, {"QUACK_HIP_W16_U": "2"}):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        assert_same(hip_table(seq, qual, read_len=300, kmers_bits=bits), want)
+        for kk in env:
+            monkeypatch.delenv(kk)
+    # without the adapter scan fixed-length reads keep 8 positions per lane (faster: memory-bound at 70 VGPRs); the
+    # 16-position build of that shape exists and is forced here
+    monkeypatch.setenv("QUACK_HIP_W16_ALWAYS", "1")
+    for L in (4, 36, 100, 300, 580):
+        s2, q2 = synth.fixed(3000, L, seed=L)
+        assert_same(hip_table(s2, q2, read_len=L), ob.accumulate_batch(s2, q2, read_len=L))
+
+
 def test_adapters_every_chunk_count_of_short_reads():
     """1..14 chunks per read: the replicated-column layouts next to the resident
     adapter tables (LDS budget), fixed and ragged"""

@@ -50,7 +50,9 @@ def test_plans_fit_the_hardware(ragged, adapters):
         assert p["n_blocks"] >= 1 and (p["dynamic"] or p["n_blocks"] == p["n_slices"]), ctx
         assert (p["unroll"], p["pipe"]) == ((4, 1) if ragged else ((1, 2) if w16 else ((2, 2) if adapters else (1, 2)))), ctx
         # fixed-length reads of a multiple of 4 bases take the dword-aligned variant, 16 positions per lane
-        assert p["aligned"] == (3 if (not ragged and max_len % 4 == 0) else 0), ctx
+        # ... and with the adapter scan fused in, 16 positions per lane
+        pairs_pay = max_len >= 64 or (max_len + 15) // 16 * 16 == (max_len + 7) // 8 * 8
+        assert p["aligned"] == ((3 if adapters and pairs_pay else 1) if (not ragged and max_len % 4 == 0) else 0), ctx
 
 
 def test_cache_line_plans():
