@@ -1431,8 +1431,15 @@ __global__ __launch_bounds__(kLenThreads) void short_length_kernel(const HistPar
 
 // starts[i] = (i % per_chunk) * stride: a strided batch restated as gapped ones (launch geometries
 // the strided kernel variant is not built for; every chunk of per_chunk reads is addressed from its own base)
-__global__ __launch_bounds__(256) void strided_starts_kernel(unsigned long long *starts, uint64_t n, uint64_t per_chunk, uint32_t stride) {
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) starts[i] = (i % per_chunk) * stride;
+// (and lengths[] is vetted on the way, as the strided length kernels do: the gapped kernels trust their lengths)
+__global__ __launch_bounds__(256) void strided_starts_kernel(unsigned long long *starts, uint64_t n, uint64_t per_chunk, uint32_t stride,
+                                                             const uint32_t *lengths, uint32_t len_limit, uint32_t *status) {
+  bool bad = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    starts[i] = (i % per_chunk) * stride;
+    bad |= lengths[i] > len_limit;
+  }
+  if (bad) atomicOr(status, kStatusBadLength);
 }
 
 // dst += src over the planar tables of two accumulators on the same device

@@ -546,8 +546,10 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
       if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));   // the scratch is shared by the accumulator's launches
       const uint64_t per_chunk = std::max<uint64_t>(1, 0x7FFFFF00ull / stride);
       const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, 4096);
-      hipLaunchKernelGGL(qk::strided_starts_kernel, dim3(blocks), dim3(256), 0, st, a->d_starts_scratch, n_reads, per_chunk, stride);
+      hipLaunchKernelGGL(qk::strided_starts_kernel, dim3(blocks), dim3(256), 0, st, a->d_starts_scratch, n_reads, per_chunk, stride,
+                         d_len, max_len, a->d_status);
       QK_HIP(hipGetLastError());
+      a->status_armed = true;
       for (uint64_t lo = 0; lo < n_reads; lo += per_chunk) {
         const uint64_t cnt = std::min<uint64_t>(per_chunk, n_reads - lo);
         rc = enqueue_batch(a, d_seq + lo * stride, d_qual + lo * stride, (const uint64_t *)a->d_starts_scratch + lo,

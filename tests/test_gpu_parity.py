@@ -535,7 +535,7 @@ def test_reads_longer_than_a_slot_make_the_slots_grow(monkeypatch, tmp_path):
 
 def test_timing_hooks_sample_every_nth_batch():
     """qk_accum_timing_enable(acc, N): HIP events around every Nth batch only; the tables are not affected"""
-    seq, qual = synth.fixed(20000, 100, seed=8)
+    seq, qual = synth.fixed(5000, 100, seed=8)       # (one batch per submit also with 1 MiB slots: tools/stress_gpu.sh)
     want = ob.accumulate_batch(np.tile(seq, 9), np.tile(qual, 9), read_len=100)
     with quack_amd.Accumulator(0) as acc:
         acc.timing(4)

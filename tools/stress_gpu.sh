@@ -10,7 +10,7 @@ for e in "QUACK_HIP_TILE=64" "QUACK_HIP_THREADS=512" "QUACK_HIP_TILE=128 QUACK_H
          "QUACK_HIP_PIPE=2 QUACK_HIP_UNROLL=2" "QUACK_HIP_UNFUSED_ADAPTERS=1" "QUACK_HIP_REPLICAS=1" "QUACK_HIP_REPLICAS=2" \
          "QUACK_HIP_ADAPT_PD=3" "QUACK_HIP_ADAPT_PD=4 QUACK_HIP_ADAPT_U=1" "QUACK_HIP_SEPARATE_COUNT=1"; do
   echo "== $e"
-  env $e timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -k "$K" 2>&1 | tail -2
+  env $e timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -rf -k "$K" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
 done
 echo "== QUACK_HIP_BATCH_MB=1"
-QUACK_HIP_BATCH_MB=1 timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -k "$K and not gapped and not promise" 2>&1 | tail -2
+QUACK_HIP_BATCH_MB=1 timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -rf -k "$K and not gapped and not promise" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
