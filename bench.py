@@ -390,9 +390,8 @@ class Job:
         for _ in range(steps):
             step()
         if exchange:
-            qd.allreduce_accumulator(acc, via_host=via_host)   # the path's single exchange (RCCL over xGMI)
-            if mate is not None:
-                qd.allreduce_accumulator(mate, via_host=via_host)
+            # the path's single exchange (RCCL over xGMI): both mates' tables in one all-reduce
+            qd.allreduce_accumulators([acc] if mate is None else [acc, mate], via_host=via_host)
         fence()
         my_elapsed = elapsed = time.perf_counter() - t0
         kernel_ms, batch_ms, launches = acc.timing_read_batch()
@@ -606,8 +605,8 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": w["label"] + ("" if args.quality == "uniform" else " [quality: %s]" % args.quality),
                        "reads_per_gpu": n * mates, "bases_per_gpu_per_step": total * mates,
-                       "resident": "HBM", "parallelism": "batch-sharded x%d, one all-reduce of u64 tables%s" % (
-                           world, " per mate" if mates == 2 else "")},
+                       "resident": "HBM", "parallelism": "batch-sharded x%d, one all-reduce of the u64 tables%s" % (
+                           world, " (both mates in one message)" if mates == 2 else "")},
             "roofline": head["roofline"],
         }
         if world > 1:
@@ -619,8 +618,8 @@ def main():
             out["ranks"] = {"world_size": dist.get_world_size(), "backend": "rccl" if args.backend == "nccl" else "gloo (rehearsal)",
                             "rccl_version": rccl, "host": _socket.gethostname(), "devices_visible": torch.cuda.device_count(),
                             "device_name": torch.cuda.get_device_name(local),
-                            "exchange": "%d x all-reduce(SUM, u64) of %d words, inside the timed region" % (
-                                mates, 97 * ((max_len + 63) // 64 * 64) + 1),
+                            "exchange": "one all-reduce(MAX) of %d geometry words + ONE all-reduce(SUM, u64) of %d x %d table words, inside the timed region" % (
+                                2 * mates, mates, 97 * ((max_len + 63) // 64 * 64) + 1),
                             "per_rank": per_rank}
             # like for like: efficiency(N) = value / (N * n1_reference.value)
             out["n1_reference"] = dict(n1_line, what="the same per-GPU workload (both mates, no exchange) on rank 0 alone, "

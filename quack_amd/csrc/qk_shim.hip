@@ -132,6 +132,7 @@ struct qk_accum {
   hipEvent_t order_ev = nullptr;
   hipStream_t order_stream = nullptr;
   bool order_valid = false;
+  bool order_recorded = false;        // order_ev already stands behind the last launch on order_stream
   // tuning
   int threads = 1024, unroll = 0, pipe = 0, tile = 0, wgs_per_cu = 0;   // 0 = automatic
   // timing
@@ -508,6 +509,20 @@ hipEvent_t get_event(qk_accum *a) {
 
 int g_ablation_mode = 0;  // set through qk_debug_set_mode (kbench only)
 
+// Launches of one accumulator run in submission order even when they come from different streams (they share the
+// queue ring, the first-hit scratch and the table's flush targets).  The event that orders them is recorded only
+// when the stream actually changes — on the accumulator's own streams, which outlive the question; a caller's stream
+// gets it right behind the launch, while it is known to exist.  (Round 2 recorded it behind every batch: a marker
+// packet between any two launches of a device-resident loop, 3-5 us of the ~14 us between two kernels.)
+int order_after_previous(qk_accum *a, hipStream_t st) {
+  if (a->order_valid && a->order_stream != st) {
+    if (!a->order_recorded) QK_HIP(hipEventRecord(a->order_ev, a->order_stream));
+    a->order_recorded = true;
+    QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));
+  }
+  return QK_OK;
+}
+
 // Enqueue the kernels of one device-resident batch on `st`.
 int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
                   const uint64_t *d_off, uint32_t *d_hit, uint64_t n_reads,
@@ -544,7 +559,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
         QK_HIP(hipMalloc((void **)&a->d_starts_scratch, n_reads * sizeof(unsigned long long)));
         a->starts_scratch_reads = n_reads;
       }
-      if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));   // the scratch is shared by the accumulator's launches
+      if ((rc = order_after_previous(a, st))) return rc;   // the scratch is shared by the accumulator's launches
       const uint64_t per_chunk = std::max<uint64_t>(1, 0x7FFFFF00ull / stride);
       const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, 4096);
       hipLaunchKernelGGL(qk::strided_starts_kernel, dim3(blocks), dim3(256), 0, st, a->d_starts_scratch, n_reads, per_chunk, stride,
@@ -560,7 +575,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
       return QK_OK;
     }
   }
-  if (a->order_valid && a->order_stream != st) QK_HIP(hipStreamWaitEvent(st, a->order_ev, 0));
+  if ((rc = order_after_previous(a, st))) return rc;
   TimedLaunch tl{};
   // (events around a launch cost ~10 us of stream time: a caller that also measures its own wall
   // clock asks for every Nth batch only)
@@ -695,7 +710,15 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     if (tl.b1 != tl.t1) QK_HIP(hipEventRecord(tl.b1, st));
     a->timed.push_back(tl);
   }
-  QK_HIP(hipEventRecord(a->order_ev, st));
+  {
+    bool own = st == a->stream;
+    for (int i = 0; i < 2; ++i) own = own || (a->slot[i].stream && st == a->slot[i].stream);
+    a->order_recorded = false;
+    if (!own) {   // a caller's stream: it may be gone by the time another stream asks
+      QK_HIP(hipEventRecord(a->order_ev, st));
+      a->order_recorded = true;
+    }
+  }
   a->order_stream = st;
   a->order_valid = true;
   a->n_reads += n_reads;
@@ -1073,6 +1096,7 @@ int qk_accum_resize_slots(qk_accum *a, uint64_t min_bytes) {
       s.busy = false;
     }
     if (s.stream) QK_HIP(hipStreamSynchronize(s.stream));
+    if (s.stream && a->order_stream == s.stream) a->order_valid = false;   // (all of it has finished; the stream goes away)
     if (s.h_seq) (void)hipHostFree(s.h_seq);
     if (s.h_qual) (void)hipHostFree(s.h_qual);
     if (s.h_off) (void)hipHostFree(s.h_off);
@@ -1088,7 +1112,6 @@ int qk_accum_resize_slots(qk_accum *a, uint64_t min_bytes) {
   }
   a->cap_bytes = round_up(min_bytes, 1u << 20);
   a->cap_reads = a->cap_bytes / 32 + 1024;
-  a->order_stream = nullptr;   // (a new slot stream may get a destroyed one's handle: the next launch waits for order_ev)
   return QK_OK;
 }
 

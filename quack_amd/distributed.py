@@ -32,24 +32,40 @@ def allreduce_planar(planar, table_len, group=None):
     return planar, common
 
 
-def allreduce_accumulator(acc, group=None, via_host=False):
-    """Sum this rank's qk_accum with every other rank's, in place (GPU path).
-    via_host=True stages the table through host memory for backends without
-    device collectives (gloo; used to rehearse the N>1 path on a one-GPU box)."""
-    max_len, _ = acc.stats()
-    gpu = torch.device("cuda", acc.device)
+def allreduce_accumulators(accs, group=None, via_host=False):
+    """Sum every rank's qk_accum with its counterparts on the other ranks, in place (GPU path) — for ALL the
+    accumulators of `accs` with one exchange: one all-reduce(MAX) of the geometries (two words per accumulator),
+    then ONE all-reduce(SUM) over their tables laid end to end (a pair's two mates travel together: quack.c:911-921
+    are two independent accumulations, their counters never mix — they only share the message).
+    via_host=True stages the tables through host memory for backends without device collectives (gloo; used to
+    rehearse the N>1 path on a one-GPU box)."""
+    accs = list(accs)
+    if not accs:
+        return accs
+    dev = accs[0].device
+    if any(a.device != dev for a in accs):
+        raise ValueError("the accumulators of one exchange live on one device (one process per GPU)")
+    gpu = torch.device("cuda", dev)
     coll = torch.device("cpu") if via_host else gpu
-    # common geometry first (one MAX over two words), so that every rank exports
-    # the same number of words
-    geo = torch.tensor([max_len, acc.table_words()], dtype=torch.int64, device=coll)
+    # common geometry first, so that every rank exports the same number of words per accumulator
+    geo = []
+    for a in accs:
+        geo += [a.stats()[0], a.table_words()]
+    geo = torch.tensor(geo, dtype=torch.int64, device=coll)
     dist.all_reduce(geo, op=dist.ReduceOp.MAX, group=group)
     geo = geo.tolist()
-    table_len = (geo[1] - 1) // QK_N_ROWS
-    acc.reserve(table_len)
-    assert acc.table_words() == QK_N_ROWS * table_len + 1
-    buf = torch.empty(acc.table_words(), dtype=torch.int64, device=gpu)
-    torch.cuda.current_stream(gpu).synchronize()   # buf is allocated before the shim's stream writes it
-    acc.export_table(buf)                          # synchronises the shim's stream before returning
+    words = []
+    for i, a in enumerate(accs):
+        table_len = (geo[2 * i + 1] - 1) // QK_N_ROWS
+        a.reserve(table_len)
+        assert a.table_words() == QK_N_ROWS * table_len + 1
+        words.append(a.table_words())
+    buf = torch.empty(sum(words), dtype=torch.int64, device=gpu)
+    torch.cuda.current_stream(gpu).synchronize()   # buf is allocated before the shim's streams write it
+    at = 0
+    for a, w in zip(accs, words):
+        a.export_table(buf[at:at + w])             # synchronises the shim's stream before returning
+        at += w
     if via_host:
         host = buf.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
@@ -58,8 +74,16 @@ def allreduce_accumulator(acc, group=None, via_host=False):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     # a finished NCCL call only orders torch's stream; the shim imports on its own stream
     torch.cuda.current_stream(gpu).synchronize()
-    acc.import_table(buf, geo[0])
-    return acc
+    at = 0
+    for i, (a, w) in enumerate(zip(accs, words)):
+        a.import_table(buf[at:at + w], geo[2 * i])
+        at += w
+    return accs
+
+
+def allreduce_accumulator(acc, group=None, via_host=False):
+    """one accumulator: see allreduce_accumulators"""
+    return allreduce_accumulators([acc], group=group, via_host=via_host)[0]
 
 
 def planar_from_bases(bases, number_of_sequences, table_len=None):

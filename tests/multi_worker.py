@@ -51,12 +51,21 @@ def main():
                 continue
             lo, hi = int(off[a]), int(off[e])
             acc.submit(seq[lo:hi], qual[lo:hi], off[a:e + 1] - off[a])
-        qd.allreduce_accumulator(acc, via_host=backend == "gloo")
+        # a second accumulator travels in the same exchange (the two mates of a pair do): every rank gives it
+        # the first 500 reads without adapters -> world x that table
+        with quack_amd.Accumulator(local, None, max_len_hint=8) as other:
+            o500 = int(off[500])
+            other.submit(seq[:o500], qual[:o500], off[:501])
+            qd.allreduce_accumulators([acc, other], via_host=backend == "gloo")
+            osd = other.finish()
         sd = acc.finish()
     ok = True
     if rank == 0:
         want, nseq = ob.accumulate_batch(seq, qual, off, kmers=k)
         ok = sd.number_of_sequences == nseq and np.array_equal(sd.bases, want)
+        o500 = int(off[500])
+        owant, on = ob.accumulate_batch(seq[:o500], qual[:o500], off[:501])
+        ok = ok and osd.number_of_sequences == world * on and np.array_equal(osd.bases, world * owant)
         json.dump({"ok": bool(ok), "world": dist.get_world_size(), "backend": backend,
                    "reads": int(sd.number_of_sequences), "max_length": int(sd.bases.shape[0]),
                    "kmer_hits": int(want[:, 96].sum())}, open(out_path, "w"))
