@@ -234,6 +234,19 @@ __device__ __forceinline__ uint32_t lds_abs_u8(uint32_t byte_addr) {
   return byte_addr & 0u;   // host pass of the single-source compile: never called
 #endif
 }
+// ... and the dword at an absolute, 4-byte-aligned LDS address.  The fused scan probes its filter this way (round 3):
+// bit (key & 31) of the dword at (key >> 5) * 4 IS bit (key & 7) of the byte at key >> 3, so the layout is the same,
+// but the probe is  v_lshrrev + v_and (address), ds_read_b32, v_bfe_i32 word, key, 1  — the bit index is the low
+// five bits of the key as it stands, where the byte probe needed a v_bfe for the address, a v_bfe for the bit index
+// and (the compiler's) v_and 0xff on what ds_read_u8 returned.
+typedef const __attribute__((address_space(3))) uint32_t lds_const_u32;
+__device__ __forceinline__ uint32_t lds_abs_u32(uint32_t byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(lds_const_u32 *)byte_addr;
+#else
+  return byte_addr & 0u;
+#endif
+}
 
 // ---- quality histogram layout and address -----------------------------------
 // The u16-pair counters of a tile are kept as PLANES of 128 rows x 32 dwords:
@@ -416,13 +429,12 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
   // the spill takes events - count.  Masked bytes are "not equal" in every
   // event, so they come out as zero.  `events` = accumulated steps since the
   // last spill (wave-uniform).  Fixed-length batches without the adapter scan
-  // go one step further: the tail masks are per-lane constants (fm0/fm1), lanes past
+  // go one step further: the tail is a per-lane constant (fixed_nc), lanes past
   // the end of the slice sit out under the exec mask and count their own
   // events (steps_v), and no per-event valid counter is needed at all.
   constexpr bool FAST_FIXED = FIXED && !SV;
-  uint32_t events = 0, steps_v = 0, fm[2 * K];
-#pragma unroll
-  for (int d = 0; d < 2 * K; ++d) fm[d] = 0xFFFFFFFFu;
+  uint32_t events = 0, steps_v = 0;
+  uint32_t fixed_nc = 0;   // FIXED: how many of the lane's 8K positions lie inside the read (the same for every read)
 
   auto spill = [&]() {
 #pragma unroll
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
       for (int b = 0; b < 4; ++b) {
         const uint32_t off = (8u * chk[d >> 1] + 4u * (d & 1) + b) * 4u;
         uint32_t v = events - ((acc_v[d] >> (8 * b)) & 0xFFu);   // acc_v counts the events in which the byte was masked
-        if (FAST_FIXED) v = ((fm[d] >> (8 * b)) & 0xFFu) ? 0u : steps_v;
+        if (FAST_FIXED) v = (uint32_t)(4 * d + b) < fixed_nc ? steps_v : 0u;
         if (v == 0) continue;  // nothing valid => no T/C/G either
         lds_add(lds_base, off, v);
         uint32_t t = (acc_t[d] >> (8 * b)) & 0xFFu;
@@ -571,16 +583,8 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
     const uint64_t room = p.total_bytes - base_al;   // total_bytes >= base_al when slice_reads > 0
     const uint32_t off_limit = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
     const uint32_t cposp = cpos + (uint32_t)(slice_base & 3ull);
-    if (FIXED) {
-      // the lane's chunks cover the same bytes of every read of the batch
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const uint32_t c0 = cpos + 8u * (uint32_t)k;
-        const uint32_t nc = (lane_on && p.read_len > c0) ? (p.read_len - c0 > 8u ? 8u : p.read_len - c0) : 0u;
-        fm[2 * k] = nc >= 4u ? 0u : (0xFFFFFFFFu << (8u * nc));
-        fm[2 * k + 1] = nc >= 8u ? 0u : (nc <= 4u ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8u * (nc - 4u))));
-      }
-    }
+    // the lane's chunks cover the same bytes of every read of a fixed-length batch
+    if (FIXED) fixed_nc = (lane_on && p.read_len > cpos) ? (p.read_len - cpos > 8u * K ? 8u * K : p.read_len - cpos) : 0u;
 
     // Fixed-length batches: one pass over the slice, read r at r*L.  Ragged
     // batches: passes of stage_reads reads; each pass first stages, in LDS, the
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
               // chunk's eight windows.  (The filter holds both 9-mers of every adapter
               // 10-mer; it sits at LDS byte 0, so the key field is the address.)
 #pragma unroll
-              for (int m = 0; m < 4; ++m) bytU[u][k][m] = lds_abs_u8(__builtin_amdgcn_ubfe(plo, 2 * (7 - 2 * m) + 3, kFusedFilterLog2 - 3));
+              for (int m = 0; m < 4; ++m) bytU[u][k][m] = lds_abs_u32((plo >> (2 * (7 - 2 * m) + 3)) & ((1u << (kFusedFilterLog2 - 3)) - 4u));
             }
           }
         }
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
             uint32_t t9[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m)   // 0 or ~0
-              t9[m] = (uint32_t)__builtin_amdgcn_sbfe((int)bytU[u][k][m], __builtin_amdgcn_ubfe(plo, 2 * (7 - 2 * m), 3), 1);
+              t9[m] = (uint32_t)__builtin_amdgcn_sbfe((int)bytU[u][k][m], plo >> (2 * (7 - 2 * m)), 1);   // (offset = the operand's low five bits)
             // windows j (suffix) and j+1 (prefix) of every 9-mer that passed
             const uint32_t h8 = (t9[0] & 0x03u) | (t9[1] & 0x0Cu) | (t9[2] & 0x30u) | (t9[3] & 0xC0u);
             hits |= h8 << (8 * k);

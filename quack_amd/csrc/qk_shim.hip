@@ -392,7 +392,8 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
         else k = adapt ? qk::hist_kernel<T, U, false, 0, true, PD, true, false, true> : qk::hist_kernel<T, U, false, 0, false, PD, true, false, true>;
       }
     }
-    // (three register sets — pipe 3 — were built and measured: 132 VGPRs' worth, so spills; 1.370 -> 1.427 ms on 10M x 300)
+    // (three register sets — pipe 3 — were built and measured twice on 10M x 300 + adapters: with spills 1.370 -> 1.427 ms;
+    // after the tail masks went (no spills) 1.31-1.36 against 1.32-1.37 ms, inside the box's own scatter)
     if (!k) return fail(QK_EINVAL, "the 16-positions-per-lane kernel is not built for unroll %d / pipe %d", U, PD);
   } else
   if (strided) {
