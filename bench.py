@@ -89,6 +89,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads (N=1: cfg3 / cfg5 / trimmed; N>1: cfg3's share)")
     ap.add_argument("--no-tiers", action="store_true", help="N=1: skip the H2D-inclusive and end-to-end CLI tiers (SURVEY 8d)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="N=1: do not measure roofline.traffic in this run (two short child passes under rocprofv3 --pmc); "
+                         "the line then carries the builder-run figure of profiles/hbm_traffic.json, labelled so")
     ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end tier's .fq.gz (x 150 bp)")
     ap.add_argument("--also-steps", type=int, default=50)
     # rehearsal on a one-GPU box: several ranks share one device and the table
@@ -449,6 +452,51 @@ def gather_ranks(ctx, r):
 
 
 # --------------------------------------------------------------------------
+def measure_traffic(workload, steps=6, warmup=2):
+    """roofline.traffic of THIS run's box and build: HBM bytes per launch of the histogram kernel from the PMC counters,
+    collected as MI355X_MICROARCH.md prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --pmc` passes (they do
+    not fit one pass), each a child process running this file for a few steps of the same workload; KB -> bytes;
+    gfx950 tallies the 128-byte requests of a coalesced stream at 64 bytes, so FETCH_SIZE is doubled.
+    -> (bytes per launch, description) or (None, why not)"""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    got = {}
+    d = tempfile.mkdtemp(prefix="quack_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(d, counter)
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--no-also", "--no-cpu-baseline",
+                   "--no-tiers", "--no-traffic"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=180)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s timed out" % counter
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed: %s" % (counter, r.stderr[-200:].decode(errors="replace"))
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "hist_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows for the histogram kernel" % counter
+            got[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    traffic = (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0
+    return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child passes of this file "
+                     "(%d + %d launches of the histogram kernel, %d steps each); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
+                     "(gfx950 tallies a coalesced stream's 128-byte requests at 64: MI355X_MICROARCH.md, HBM)" % (
+                         got["FETCH_SIZE"][1], got["WRITE_SIZE"][1], steps))
+
+
 # SURVEY 8d asks for three tiers; `value` is (i), kernels over batches resident in HBM.  The other two:
 def tier_h2d(ctx, n_batches=48):
     """(ii) H2D-inclusive: pre-parsed host batches in the accumulator's two pinned slots, qk_accum_acquire /
@@ -662,9 +710,23 @@ def main():
                 also[nm] = entry
                 del j2
                 torch.cuda.empty_cache()
+                if not args.no_traffic:
+                    tr, how = measure_traffic(nm)
+                    if tr is not None:
+                        entry["roofline"].update(traffic=tr, traffic_source=how,
+                                                 traffic_over_algorithmic=tr / entry["roofline"]["algorithmic_bytes_per_launch"])
             out["also"] = also
         if not args.no_cpu_baseline:
             out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baselines(np, job.b, w, job.ads)
+        if not args.no_traffic:
+            # (after everything timed: the child passes have the GPU to themselves, and so had the timed loops)
+            tr, how = measure_traffic(name)
+            if tr is not None:
+                out["roofline"]["traffic"] = tr
+                out["roofline"]["traffic_source"] = how
+                out["roofline"]["traffic_over_algorithmic"] = tr / out["roofline"]["algorithmic_bytes_per_launch"]
+            else:
+                out["roofline"]["traffic_note"] = "live measurement unavailable (%s); the figure is the builder-run one" % how
         if args.workload == "auto" and not args.no_tiers:
             # "report all three" — (i) is `value`; neither of these is ever `value`
             del job
