@@ -561,7 +561,8 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
         a->starts_scratch_reads = n_reads;
       }
       if ((rc = order_after_previous(a, st))) return rc;   // the scratch is shared by the accumulator's launches
-      const uint64_t per_chunk = std::max<uint64_t>(1, 0x7FFFFF00ull / stride);
+      uint64_t per_chunk = std::max<uint64_t>(1, 0x7FFFFF00ull / stride);
+      if (const int t = env_int("QUACK_HIP_STRIDED_CHUNK_READS", 0)) per_chunk = std::min<uint64_t>(per_chunk, (uint64_t)t);   // (tests: several chunks without 2 GiB)
       const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, 4096);
       hipLaunchKernelGGL(qk::strided_starts_kernel, dim3(blocks), dim3(256), 0, st, a->d_starts_scratch, n_reads, per_chunk, stride,
                          d_len, max_len, a->d_status);

@@ -789,6 +789,24 @@ def test_strided_batches_under_tuning_overrides(cfg, env, monkeypatch):
         assert_same((sd.bases, want[1]), (2 * want[0], want[1]))
 
 
+def test_strided_fallback_in_several_chunks(monkeypatch):
+    """a strided batch restated as gapped ones is cut where a gapped batch would pass 2 GiB; here at 3000 reads"""
+    import torch
+    monkeypatch.setenv("QUACK_HIP_STRIDED_CHUNK_READS", "3000")
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    n, stride = 10000, 152
+    seq, qual, off = synth.ragged(n, 90, 150, seed=78, q_lo=1, q_hi=60)
+    s2, q2, lens = strided_from_ragged(seq, qual, off, stride)
+    want = ob.accumulate_batch(seq, qual, off, kmers=k)
+    with quack_amd.Accumulator(0, ob.kmers_to_bitset(k)) as acc:
+        acc.configure(unroll=2)
+        d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+        acc.submit_device_strided(d_s, d_q, torch.from_numpy(lens.astype(np.int32)).cuda(), n, stride, int(lens.max()))
+        sd = acc.finish()
+    assert_same((sd.bases, sd.number_of_sequences), want)
+
+
 def test_device_side_length_beyond_the_declared_maximum_is_reported():
     """lengths[] of a device-resident strided batch cannot be vetted by the host: a read longer than the caller
     declared must fail the next sync, and must not write outside the table"""
