@@ -124,9 +124,24 @@ struct qk_accum {
   // from different streams: they share the queue ring, the first-hit scratch
   // and the table's flush targets
   // long ragged reads: reads ordered by the tiles they reach (qk::reach_* kernels)
-  uint32_t *d_order = nullptr;        // [order_cap]
-  uint64_t order_cap = 0;
-  uint32_t *d_reach = nullptr;        // [kReachMaxTiles] reach | [kReachMaxTiles + 1] counts | [kReachMaxTiles + 1] cursor
+  // (two sets, used in turn: the pre-pass of batch k+1 may run — on the side stream below — while the histogram
+  // kernel of batch k still reads its own)
+  uint32_t *d_order[2] = {nullptr, nullptr};        // [order_cap]
+  uint64_t order_cap[2] = {0, 0};
+  uint32_t *d_reach[2] = {nullptr, nullptr};        // [kReachMaxTiles] reach | [kReachMaxTiles + 1] counts | [kReachMaxTiles + 1] cursor
+  unsigned set_turn = 0;
+  // Side stream (round 3): the reach sort of long ragged reads, which only reads the batch's lengths, runs here when
+  // the batch was submitted on the accumulator's OWN stream
+  // (device-resident feed: the caller's buffers are complete when the call is made, that stream is ordered with
+  // nothing of the caller's).  It then overlaps the tail of the previous batch's histogram kernel (its flush, its
+  // teardown, in which the CUs drain) instead of standing between two kernels — as far as the CUs have room: the
+  // histogram kernel holds every VGPR of a CU until its workgroup retires.  Measured on 1-20 kb reads: 7 of the 30 us
+  // around a 0.58 ms kernel (step 0.619 -> 0.612 ms).  Batches from the pinned slots keep everything on the slot's
+  // stream (their copies come first, and the two slots overlap each other anyway).
+  hipStream_t side = nullptr;
+  hipEvent_t side_done = nullptr;                   // behind a pre-pass on `side`: the histogram kernel waits for it
+  hipEvent_t set_free[2] = {nullptr, nullptr};      // behind the histogram kernel that read set i
+  bool set_busy[2] = {false, false};
   uint32_t *d_status = nullptr;       // device word: bit 0 = an "aligned" batch was not aligned
   bool status_armed = false;
   hipEvent_t order_ev = nullptr;
@@ -642,9 +657,16 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.reach = nullptr;
   hp.lengths_done = 0;
   // (with two or three tiles nearly every read reaches every tile: nothing to gain from sorting)
+  // kernels that only read the batch's lengths go to the side stream when the batch came in on the accumulator's own
+  // stream (see qk_accum::side)
+  const bool aside = st == a->stream && a->side != nullptr && !getenv("QUACK_HIP_NO_SIDE");
+  hipStream_t pre = aside ? a->side : st;
+  int set = -1;
   if (strided) {
     // strided batches have no staging pass that could count the lengths on the way
-    // (ragged batches of several tiles: hist_kernel counts a read's length in the tile it ends in)
+    // (ragged batches of several tiles: hist_kernel counts a read's length in the tile it ends in).
+    // (on the side stream it would run BESIDE this batch's histogram kernel — nothing orders the two — and was measured:
+    // the step 1 % shorter, the histogram kernel's own time 3 % longer, 0.540 -> 0.555-0.56 ms; it stays in line)
     const unsigned lb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 8192, (uint64_t)a->n_cu));
     if (strided && stride <= qk::kShortLen)
       hipLaunchKernelGGL(qk::short_length_kernel, dim3(lb), dim3(qk::kLenThreads), 0, st, hp);
@@ -654,30 +676,37 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     hp.lengths_done = 1;
   }
   if (pl.sorted) {
-    if (a->order_cap < n_reads) {
+    set = (int)(a->set_turn++ & 1u);
+    if (a->order_cap[set] < n_reads) {
       QK_HIP(hipDeviceSynchronize());
-      if (a->d_order) QK_HIP(hipFree(a->d_order));
-      a->d_order = nullptr;
-      a->order_cap = 0;
-      QK_HIP(hipMalloc((void **)&a->d_order, n_reads * sizeof(uint32_t)));
-      a->order_cap = n_reads;
+      if (a->d_order[set]) QK_HIP(hipFree(a->d_order[set]));
+      a->d_order[set] = nullptr;
+      a->order_cap[set] = 0;
+      QK_HIP(hipMalloc((void **)&a->d_order[set], n_reads * sizeof(uint32_t)));
+      a->order_cap[set] = n_reads;
     }
     // reach | counts | cursor | done | prefix (u64, 8-byte aligned: the word count before it is even)
     const size_t reach_words = 3 * (size_t)qk::kReachMaxTiles + 4 + 2 * ((size_t)qk::kReachMaxTiles + 1);
-    if (!a->d_reach) {
-      QK_HIP(hipMalloc((void **)&a->d_reach, reach_words * sizeof(uint32_t)));
-      QK_HIP(hipMemsetAsync(a->d_reach, 0, reach_words * sizeof(uint32_t), st));   // counts and `done` stay zero between launches
+    if (!a->d_reach[set]) {
+      QK_HIP(hipMalloc((void **)&a->d_reach[set], reach_words * sizeof(uint32_t)));
+      QK_HIP(hipMemset(a->d_reach[set], 0, reach_words * sizeof(uint32_t)));   // counts and `done` stay zero between launches
     }
-    uint32_t *reach = a->d_reach, *counts = reach + qk::kReachMaxTiles, *cursor = counts + qk::kReachMaxTiles + 1;
+    uint32_t *reach = a->d_reach[set], *counts = reach + qk::kReachMaxTiles, *cursor = counts + qk::kReachMaxTiles + 1;
     uint32_t *done = cursor + qk::kReachMaxTiles + 1;
     unsigned long long *prefix = reinterpret_cast<unsigned long long *>(reach + 3 * (size_t)qk::kReachMaxTiles + 4);
     const size_t lds = (pl.n_tiles + 2) * sizeof(uint32_t);
     // few blocks: every block costs one same-address atomic per bucket (~15 ns each, serialised)
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 1024, (uint64_t)a->n_cu * 4));
-    hipLaunchKernelGGL(qk::reach_count_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, st, hp, counts, done, reach, cursor, prefix);
-    hipLaunchKernelGGL(qk::reach_scatter_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, st, hp, cursor, a->d_order);
+    // the set's previous user — the histogram kernel of two batches ago — must have finished with it
+    if (a->set_busy[set]) QK_HIP(hipStreamWaitEvent(pre, a->set_free[set], 0));
+    hipLaunchKernelGGL(qk::reach_count_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, pre, hp, counts, done, reach, cursor, prefix);
+    hipLaunchKernelGGL(qk::reach_scatter_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, pre, hp, cursor, a->d_order[set]);
     QK_HIP(hipGetLastError());
-    hp.order = a->d_order;
+    if (aside) {
+      QK_HIP(hipEventRecord(a->side_done, a->side));
+      QK_HIP(hipStreamWaitEvent(st, a->side_done, 0));
+    }
+    hp.order = a->d_order[set];
     hp.reach = reach;
     hp.tile_prefix = prefix;
   }
@@ -711,6 +740,10 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   if (timed) {
     if (tl.b1 != tl.t1) QK_HIP(hipEventRecord(tl.b1, st));
     a->timed.push_back(tl);
+  }
+  if (set >= 0) {   // the next user of this set of order / reach buffers waits for the kernels above
+    QK_HIP(hipEventRecord(a->set_free[set], st));
+    a->set_busy[set] = true;
   }
   {
     bool own = st == a->stream;
@@ -968,6 +1001,10 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
     a->wgs_per_cu = env_int("QUACK_HIP_WGS_PER_CU", a->wgs_per_cu);
     lap.mark("device");
     if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&a->side_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&a->set_free[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&a->set_free[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&a->order_ev, hipEventDisableTiming) != hipSuccess) {
       rc = fail(QK_EHIP, "hipStreamCreate / hipEventCreate failed");
       break;
@@ -1039,8 +1076,13 @@ void qk_accum_destroy(qk_accum *a) {
   for (auto e : a->event_pool) (void)hipEventDestroy(e);
   if (a->d_queues) (void)hipFree(a->d_queues);
   if (a->d_status) (void)hipFree(a->d_status);
-  if (a->d_order) (void)hipFree(a->d_order);
-  if (a->d_reach) (void)hipFree(a->d_reach);
+  for (int i = 0; i < 2; ++i) {
+    if (a->d_order[i]) (void)hipFree(a->d_order[i]);
+    if (a->d_reach[i]) (void)hipFree(a->d_reach[i]);
+    if (a->set_free[i]) (void)hipEventDestroy(a->set_free[i]);
+  }
+  if (a->side_done) (void)hipEventDestroy(a->side_done);
+  if (a->side) (void)hipStreamDestroy(a->side);
   if (a->d_hit_scratch) (void)hipFree(a->d_hit_scratch);
   if (a->d_starts_scratch) (void)hipFree(a->d_starts_scratch);
   if (a->d_kmer_bits) (void)hipFree(a->d_kmer_bits);
@@ -1407,6 +1449,7 @@ int qk_accum_sync(qk_accum *a) {
     QK_HIP(hipDeviceSynchronize());
   } else {
     QK_HIP(hipStreamSynchronize(a->stream));
+    if (a->side) QK_HIP(hipStreamSynchronize(a->side));
     for (int i = 0; i < 2; ++i)
       if (a->slot[i].stream) QK_HIP(hipStreamSynchronize(a->slot[i].stream));
   }
