@@ -329,8 +329,11 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 // for the predecessor codes, the candidate vote) is paid once per 16 positions.  The LDS image keeps its 8-position
 // chunk layout; only the column order changes (even chunks first, so that the lanes of one counting instruction
 // still touch consecutive dwords).
+// (the long-read build — ragged, W16, no adapter scan — is held to 120 VGPRs: four of its waves then leave 32 registers of
+// a SIMD free, which is what the waves of the NEXT batch's reach pre-pass (12-16 VGPRs, 2 KiB of LDS) need to run beside it
+// on the side stream instead of waiting for a workgroup to retire)
 template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false>
-__global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
+__device__ __forceinline__ void hist_body(const HistParams &p) {
   static_assert(!SV || (FIXED && AL), "strided batches are a variant of the dword-aligned fixed-length path");
   static_assert(!W16 || (AL && !SV && MODE == 0), "16 positions per lane: dword-aligned batches only");
   constexpr bool STAGED = !FIXED;   // ragged batches: the read list is staged in LDS pass by pass
@@ -1196,6 +1199,15 @@ __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PE
 #endif
   if (cur_tile != 0xFFFFFFFFu) flush(cur_tile);
 }
+
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false>
+__global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
+  hist_body<T, U, FIXED, MODE, ADAPT, PD, AL, SV, W16>(p);
+}
+
+// (A build of the long-read variant held to 120 VGPRs — four of its waves then leave 32 registers of a SIMD free, room for
+// the waves of the next batch's reach pre-pass (12-16 VGPRs) on the side stream — was measured, four alternations of 200
+// steps on one box: 0.6100 ms per config-5 step against 0.6091 with all 126; not kept.)
 
 // ---- pre-pass of long ragged batches: reads ordered by the tiles they reach --
 // bucket k = reads that reach exactly k tiles (k = ceil(len / tile_pos), capped);

@@ -135,8 +135,8 @@ struct qk_accum {
   // (device-resident feed: the caller's buffers are complete when the call is made, that stream is ordered with
   // nothing of the caller's).  It then overlaps the tail of the previous batch's histogram kernel (its flush, its
   // teardown, in which the CUs drain) instead of standing between two kernels — as far as the CUs have room: the
-  // histogram kernel holds every VGPR of a CU until its workgroup retires.  Measured on 1-20 kb reads: 7 of the 30 us
-  // around a 0.58 ms kernel (step 0.619 -> 0.612 ms).  Batches from the pinned slots keep everything on the slot's
+  // histogram kernel holds every VGPR of a CU until its workgroup retires.  Measured on 1-20 kb reads, four alternations
+  // of 200 steps on one box: 0.6128 -> 0.6100 ms per step (3-4 of the 30 us around a 0.58 ms kernel).  Batches from the pinned slots keep everything on the slot's
   // stream (their copies come first, and the two slots overlap each other anyway).
   hipStream_t side = nullptr;
   hipEvent_t side_done = nullptr;                   // behind a pre-pass on `side`: the histogram kernel waits for it
