@@ -9,10 +9,15 @@
  * rc 139).  Here every input is accumulated first; on any failure a message
  * goes to stderr, nothing to stdout, and the exit code is 1.
  */
+#include <errno.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "quack_host.h"
 
@@ -34,6 +39,115 @@ static void *file_job_main(void *arg) {
   j->rc = qkh_accumulate_file(j->path, j->bitset, j->devs, j->n_devs, &j->tab, &j->max_len, &j->n_reads);
   if (j->rc) snprintf(j->err, sizeof j->err, "%s", qkh_last_error());
   return NULL;
+}
+
+/* the one or two read_fastq() calls of a run */
+static void run_jobs(file_job *jobs, int n_jobs) {
+  pthread_t th;
+  int threaded = 0;
+  if (n_jobs == 2 && pthread_create(&th, NULL, file_job_main, &jobs[1]) == 0) threaded = 1;
+  file_job_main(&jobs[0]);
+  if (n_jobs == 2) {
+    if (threaded) pthread_join(th, NULL);
+    else file_job_main(&jobs[1]);
+  }
+}
+
+static int write_all(int fd, const void *buf, size_t n) {
+  const char *p = buf;
+  while (n) {
+    ssize_t k = write(fd, p, n);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) return -1;
+    p += k;
+    n -= (size_t)k;
+  }
+  return 0;
+}
+static int read_all(int fd, void *buf, size_t n) {
+  char *p = buf;
+  while (n) {
+    ssize_t k = read(fd, p, n);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) return -1;
+    p += k;
+    n -= (size_t)k;
+  }
+  return 0;
+}
+
+/* The accumulation in a WORKER PROCESS (round 3).  A process that has used the GPU takes 0.13-0.15 s to exit —
+ * the kernel driver tearing down its queues, pinned and device memory — a quarter of a run on a 0.6-Gbase file, and
+ * nothing the user waits for serves a purpose: the counters are complete.  So everything that touches HIP happens in
+ * a child forked before the runtime starts; it sends the tables back through a pipe (116 KB at 150 bp), closes its
+ * standard streams — so that nobody reading them waits for it — and exits on its own time, while this process, which
+ * never loaded the runtime, transforms, draws and returns.  QUACK_NO_FORK=1 (or QUACK_FULL_TEARDOWN=1, the leak
+ * checkers' mode) keeps everything in one process.  Returns 0 when the jobs' results are in `jobs`, -1 when there is
+ * no worker (the caller then runs them itself). */
+static int run_jobs_in_worker(file_job *jobs, int n_jobs) {
+  int fd[2];
+  pid_t pid;
+  if (getenv("QUACK_NO_FORK") || getenv("QUACK_FULL_TEARDOWN")) return -1;
+  if (pipe(fd)) return -1;
+  fflush(stdout);
+  fflush(stderr);
+  pid = fork();
+  if (pid < 0) {
+    close(fd[0]);
+    close(fd[1]);
+    return -1;
+  }
+  if (pid == 0) {
+    int ok = 1;
+    close(fd[0]);
+    (void)dup2(2, 1);   /* the document is the parent's to write: whatever a library prints to stdout here goes to stderr */
+    run_jobs(jobs, n_jobs);
+    for (int k = 0; k < n_jobs && ok; k++) {
+      ok = !write_all(fd[1], &jobs[k].rc, sizeof jobs[k].rc) && !write_all(fd[1], jobs[k].err, sizeof jobs[k].err) &&
+           !write_all(fd[1], &jobs[k].max_len, sizeof jobs[k].max_len) && !write_all(fd[1], &jobs[k].n_reads, sizeof jobs[k].n_reads);
+      if (ok && !jobs[k].rc && jobs[k].max_len)
+        ok = !write_all(fd[1], jobs[k].tab, (size_t)jobs[k].max_len * sizeof(qk_base_info));
+    }
+    fflush(stderr);
+    close(fd[1]);
+    /* nobody waits for this process any more: let go of the standard streams before the slow part of exiting */
+    close(0);
+    close(1);
+    close(2);
+    _exit(ok ? 0 : 3);
+  }
+  close(fd[1]);
+  for (int k = 0; k < n_jobs; k++) {
+    jobs[k].tab = NULL;
+    if (read_all(fd[0], &jobs[k].rc, sizeof jobs[k].rc) || read_all(fd[0], jobs[k].err, sizeof jobs[k].err) ||
+        read_all(fd[0], &jobs[k].max_len, sizeof jobs[k].max_len) || read_all(fd[0], &jobs[k].n_reads, sizeof jobs[k].n_reads)) {
+      /* the worker is gone without a word: say how it ended */
+      int st = 0;
+      (void)waitpid(pid, &st, 0);
+      jobs[k].rc = -1;
+      jobs[k].max_len = 0;
+      if (WIFSIGNALED(st)) snprintf(jobs[k].err, sizeof jobs[k].err, "%s: the accumulation process was killed by signal %d", jobs[k].path, WTERMSIG(st));
+      else snprintf(jobs[k].err, sizeof jobs[k].err, "%s: the accumulation process ended without a result (status %d)", jobs[k].path, WEXITSTATUS(st));
+      for (int j = k + 1; j < n_jobs; j++) {
+        jobs[j].rc = -1;
+        jobs[j].max_len = 0;
+        snprintf(jobs[j].err, sizeof jobs[j].err, "%s: not read", jobs[j].path);
+      }
+      break;
+    }
+    jobs[k].err[sizeof jobs[k].err - 1] = 0;
+    if (!jobs[k].rc && jobs[k].max_len) {
+      jobs[k].tab = calloc(jobs[k].max_len, sizeof(qk_base_info));
+      if (!jobs[k].tab || read_all(fd[0], jobs[k].tab, (size_t)jobs[k].max_len * sizeof(qk_base_info))) {
+        free(jobs[k].tab);
+        jobs[k].tab = NULL;
+        jobs[k].rc = -1;
+        snprintf(jobs[k].err, sizeof jobs[k].err, "%s: the counters did not arrive", jobs[k].path);
+      }
+    }
+  }
+  close(fd[0]);
+  return 0;
 }
 
 static const char *const k_version = "quack 1.1.1";   /* quack.c:54 */
@@ -137,8 +251,7 @@ int qkh_main(int argc, char **argv) {
   /* accumulate first (quack.c:911,917), print afterwards */
   {
     file_job jobs[2];
-    pthread_t th;
-    int n_jobs = paired ? 2 : 1, threaded = 0;
+    int n_jobs = paired ? 2 : 1;
     memset(jobs, 0, sizeof jobs);
     jobs[0].path = paired ? o.forward : o.unpaired;
     jobs[1].path = o.reverse;
@@ -147,12 +260,7 @@ int qkh_main(int argc, char **argv) {
       jobs[k].devs = devs;
       jobs[k].n_devs = n_devs;
     }
-    if (paired && pthread_create(&th, NULL, file_job_main, &jobs[1]) == 0) threaded = 1;
-    file_job_main(&jobs[0]);
-    if (paired) {
-      if (threaded) pthread_join(th, NULL);
-      else file_job_main(&jobs[1]);
-    }
+    if (run_jobs_in_worker(jobs, n_jobs)) run_jobs(jobs, n_jobs);
     for (int k = 0; k < n_jobs; k++) {
       tab[k] = jobs[k].tab;
       max_len[k] = jobs[k].max_len;
