@@ -102,6 +102,7 @@ static int run_jobs_in_worker(file_job *jobs, int n_jobs) {
     close(fd[0]);
     (void)dup2(2, 1);   /* the document is the parent's to write: whatever a library prints to stdout here goes to stderr */
     run_jobs(jobs, n_jobs);
+    if (getenv("QUACK_TEST_WORKER_DIES")) abort();   /* (tests: the parent's report of a worker that is gone) */
     for (int k = 0; k < n_jobs && ok; k++) {
       ok = !write_all(fd[1], &jobs[k].rc, sizeof jobs[k].rc) && !write_all(fd[1], jobs[k].err, sizeof jobs[k].err) &&
            !write_all(fd[1], &jobs[k].max_len, sizeof jobs[k].max_len) && !write_all(fd[1], &jobs[k].n_reads, sizeof jobs[k].n_reads);

@@ -53,6 +53,27 @@ def test_whole_host_reproduces_the_reference_svg(quack_double, name, argv):
         assert r.stderr == cases.golden_err(name)
 
 
+def test_worker_process(quack_double):
+    """by default the CLI accumulates in a worker process forked before the HIP runtime starts (the 0.13 s a GPU
+    process takes to exit are then not the caller's): same bytes as in one process, for a single file, a pair (two
+    tables through the pipe), long reads (a 31 MB table), a file without reads; and a worker that dies is reported —
+    message on stderr, nothing on stdout, exit code 1"""
+    base = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", QUACK_NO_EARLY="1")
+    cwd = os.path.join(cases.G, "inputs")
+    for name in ("uniform100_adapters", "paired_adapters_named", "long40", "badcrc800"):
+        argv = dict(cases.load())[name]
+        r = subprocess.run([quack_double] + argv, capture_output=True, cwd=cwd, env=base, timeout=300)
+        one = subprocess.run([quack_double] + argv, capture_output=True, cwd=cwd, env=dict(base, QUACK_NO_FORK="1"), timeout=300)
+        assert r.returncode == 0 and one.returncode == 0, (name, r.stderr[-2000:])
+        assert r.stdout == one.stdout == cases.golden_svg(name) and r.stderr == one.stderr == cases.golden_err(name), name
+    r = subprocess.run([quack_double, "-u", "/dev/null"], capture_output=True, cwd=cwd, env=base, timeout=60)
+    assert r.returncode == 1 and r.stdout == b"" and b"no sequence data" in r.stderr
+    r = subprocess.run([quack_double, "-u", "no_such_file.fq"], capture_output=True, cwd=cwd, env=base, timeout=60)
+    assert r.returncode == 1 and r.stdout == b"" and b"cannot open" in r.stderr
+    r = subprocess.run([quack_double, "-u", "uniform100.fq"], capture_output=True, cwd=cwd, env=dict(base, QUACK_TEST_WORKER_DIES="1"), timeout=60)
+    assert r.returncode == 1 and r.stdout == b"" and b"killed by signal 6" in r.stderr, r.stderr
+
+
 def test_long_reads_switch_to_cache_line_batches(quack_double, tmp_path):
     """the pipeline pads long-read batches (QK_BATCH_ALIGNED128) from the second batch on"""
     g = np.random.default_rng(4)
