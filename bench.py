@@ -452,6 +452,9 @@ def gather_ranks(ctx, r):
 
 
 # --------------------------------------------------------------------------
+_traffic_broken = None   # why a child pass failed: no further pass is attempted in this run (a hung profiler must not cost minutes)
+
+
 def measure_traffic(workload, steps=6, warmup=2):
     """roofline.traffic of THIS run's box and build: HBM bytes per launch of the histogram kernel from the PMC counters,
     collected as MI355X_MICROARCH.md prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --pmc` passes (they do
@@ -462,9 +465,13 @@ def measure_traffic(workload, steps=6, warmup=2):
     import glob
     import shutil
     import tempfile
+    global _traffic_broken
+    if _traffic_broken:
+        return None, _traffic_broken
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
-        return None, "rocprofv3 not found"
+        _traffic_broken = "rocprofv3 not found"
+        return None, _traffic_broken
     got = {}
     d = tempfile.mkdtemp(prefix="quack_pmc_", dir="/tmp")
     try:
@@ -475,11 +482,13 @@ def measure_traffic(workload, steps=6, warmup=2):
                    "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--no-also", "--no-cpu-baseline",
                    "--no-tiers", "--no-traffic"]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=180)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=90)
             except subprocess.TimeoutExpired:
-                return None, "rocprofv3 --pmc %s timed out" % counter
+                _traffic_broken = "rocprofv3 --pmc %s timed out" % counter
+                return None, _traffic_broken
             if r.returncode != 0:
-                return None, "rocprofv3 --pmc %s failed: %s" % (counter, r.stderr[-200:].decode(errors="replace"))
+                _traffic_broken = "rocprofv3 --pmc %s failed: %s" % (counter, r.stderr[-200:].decode(errors="replace"))
+                return None, _traffic_broken
             vals = []
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
