@@ -87,7 +87,9 @@ static int read_all(int fd, void *buf, size_t n) {
 static int run_jobs_in_worker(file_job *jobs, int n_jobs) {
   int fd[2];
   pid_t pid;
-  if (getenv("QUACK_NO_FORK") || getenv("QUACK_FULL_TEARDOWN")) return -1;
+  /* only in a process that said it is quack's own and about to exit (main.c): a caller that runs qkh_main inside a larger
+   * program may have the HIP runtime up already, and a process must not fork behind it */
+  if (!qkh_process_exits() || getenv("QUACK_NO_FORK") || getenv("QUACK_FULL_TEARDOWN")) return -1;
   if (pipe(fd)) return -1;
   fflush(stdout);
   fflush(stderr);

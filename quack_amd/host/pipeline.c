@@ -34,6 +34,7 @@ static int host_fail(const char *fmt, ...) {
 
 static int g_process_exits;
 void qkh_process_exits_after_this(int on) { g_process_exits = on; }
+int qkh_process_exits(void) { return g_process_exits; }
 
 static double now_s(void) {
   struct timespec ts;

@@ -73,6 +73,7 @@ int qkh_read_adapters(const char *path, uint32_t *bitset);
 /* CLI only: the process exits (by _exit) right after the results are printed, so a successful
  * qkh_accumulate_file leaves its accumulators, reader threads and the HIP runtime to the OS. */
 void qkh_process_exits_after_this(int on);
+int qkh_process_exits(void);   /* ... as the caller said */
 int qkh_accumulate_file(const char *path, const uint32_t *bitset,
                         const int *devices, int n_devices,
                         qk_base_info **bases_out, uint64_t *max_len,
