@@ -89,11 +89,14 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra workloads (N=1: cfg3 / cfg5 / trimmed; N>1: cfg3's share)")
     ap.add_argument("--no-tiers", action="store_true", help="N=1: skip the H2D-inclusive and end-to-end CLI tiers (SURVEY 8d)")
+    ap.add_argument("--no-steady", action="store_true", help="N=1: skip the extra steady-state loop (roofline.steady_state)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="N=1: do not measure roofline.traffic in this run (two short child passes under rocprofv3 --pmc); "
                          "the line then carries the builder-run figure of profiles/hbm_traffic.json, labelled so")
     ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end tier's .fq.gz (x 150 bp)")
     ap.add_argument("--also-steps", type=int, default=50)
+    ap.add_argument("--also-warmup", type=int, default=100,
+                    help="untimed passes in front of each `also` workload's timed ones: past the ~35 ms power transient of a kernel's first launches")
     # rehearsal on a one-GPU box: several ranks share one device and the table
     # exchange goes through gloo (the driver's runs use the defaults: nccl = RCCL)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -480,7 +483,7 @@ def measure_traffic(workload, steps=6, warmup=2):
             out = os.path.join(d, counter)
             cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                    "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--no-also", "--no-cpu-baseline",
-                   "--no-tiers", "--no-traffic"]
+                   "--no-tiers", "--no-traffic", "--no-steady"]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=90)
             except subprocess.TimeoutExpired:
@@ -704,9 +707,9 @@ def main():
         w3["n"] = w3["n"] // world
         w3["label"] = "config 3's share: 10M-read 300 bp + adapters (25%% of the reads spliced) over %d GPUs = %d reads per GPU" % (world, w3["n"])
         job3 = Job(ctx, "cfg3", w3, seed=3 + rank, seed_mate=0)
-        alone = job3.run(args.also_steps, 15, world=1, exchange=False) if rank == 0 else None
+        alone = job3.run(args.also_steps, args.also_warmup, world=1, exchange=False) if rank == 0 else None
         dist.barrier()
-        r3 = job3.run(args.also_steps, 15, world=world, exchange=True)
+        r3 = job3.run(args.also_steps, args.also_warmup, world=world, exchange=True)
         ranks3 = gather_ranks(ctx, r3)
         if rank == 0:
             e = job3.line(r3, world, None)
@@ -718,12 +721,23 @@ def main():
         del job3
         torch.cuda.empty_cache()
 
+    if rank == 0 and world == 1 and not args.no_steady:
+        # Outside the contract's W + K steps, reported beside them and never as `value`: the same kernel once the part's power
+        # management has settled on it.  A fresh process's launches run 514, 490, 498, 499 us, climb to 560 at launch 10 and decay
+        # to 487 +- 3 from launch 70 on (profiles/r03_first_launches.log): `--warmup 5 --steps 20` times launches 6-25.
+        st = job.run(100, 70)
+        out["roofline"]["steady_state"] = {
+            "kernel_ms": st["kernel_ms"], "kernel_ms_min": st["kernel_ms_min"], "kernel_ms_max": st["kernel_ms_max"],
+            "frac": job.alg_bytes / (st["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": st["elapsed"] / st["steps"] * 1e3,
+            "warmup": st["warmup"], "steps": st["steps"], "launches_timed": st["launches"],
+            "what": "a second loop on fresh accumulators, 70 untimed + 100 timed passes: the kernel after the power transient of its "
+                    "first ~70 launches; not the contract's figure (that is roofline.frac, from the W + K steps above)"}
     if rank == 0 and world == 1:
         if args.workload == "auto" and not args.no_also:
             also = {}
             for nm in ("cfg3", "cfg5", "trimmed"):
                 j2 = Job(ctx, nm, dict(WORKLOADS[nm]), seed={"cfg3": 3, "cfg5": 6, "trimmed": 7}[nm], seed_mate=0)
-                entry = j2.line(j2.run(args.also_steps, 15), 1, traffic_tab.get(nm))
+                entry = j2.line(j2.run(args.also_steps, args.also_warmup), 1, traffic_tab.get(nm))
                 if nm == "cfg3":
                     entry["reads_with_spliced_adapter"] = j2.b["spliced"]
                 if not args.no_cpu_baseline:

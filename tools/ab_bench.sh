@@ -11,7 +11,7 @@ for rep in $(seq 1 ${AB_REPS:-2}); do
   for v in A B; do
     cp /tmp/ab_$v.so quack_amd/libquack_hip.so
     for w in "$@"; do
-      python bench.py --workload $w --no-also --no-cpu-baseline --no-tiers --no-traffic $AB_ARGS 2>/dev/null | tail -1 > /tmp/ab_line.json
+      python bench.py --workload $w --no-also --no-cpu-baseline --no-tiers --no-traffic --no-steady $AB_ARGS 2>/dev/null | tail -1 > /tmp/ab_line.json
       python - "$v" "$w" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab_line.json"))

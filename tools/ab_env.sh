@@ -8,7 +8,7 @@ for rep in 1 2; do
   for v in A B; do
     cp /tmp/ab_$v.so quack_amd/libquack_hip.so
     [ $v = B ] && ee="$benv" || ee=""
-    env $ee python bench.py --workload $w --no-also --no-cpu-baseline --no-tiers --no-traffic "$@" 2>/tmp/ab_err.txt | tail -1 > /tmp/ab_line.json
+    env $ee python bench.py --workload $w --no-also --no-cpu-baseline --no-tiers --no-traffic --no-steady "$@" 2>/tmp/ab_err.txt | tail -1 > /tmp/ab_line.json
     python - "$v $ee" "$w" <<'PY'
 import json, sys
 try:

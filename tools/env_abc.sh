@@ -7,7 +7,7 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done
 for rep in $(seq 1 ${REPS:-4}); do
   for e in "${envs[@]}"; do
     [ "$e" = "-" ] && ee="" || ee="$e"
-    env $ee python bench.py --workload $w --no-also --no-cpu-baseline --no-tiers --no-traffic "$@" 2>/tmp/ab_err.txt | tail -1 > /tmp/ab_line.json
+    env $ee python bench.py --workload $w --no-also --no-cpu-baseline --no-tiers --no-traffic --no-steady "$@" 2>/tmp/ab_err.txt | tail -1 > /tmp/ab_line.json
     python - "${ee:-(default)}" "$w" <<'PY'
 import json, sys
 try:

@@ -5,7 +5,7 @@ w=$1; args=$2; shift 2
 for rep in 1 2; do
   for e in "$@"; do
     [ "$e" = "-" ] && ee="" || ee="$e"
-    env $ee python bench.py --workload $w --no-also --no-cpu-baseline --no-tiers --no-traffic $args 2>/tmp/env_err.txt | tail -1 > /tmp/env_line.json
+    env $ee python bench.py --workload $w --no-also --no-cpu-baseline --no-tiers --no-traffic --no-steady $args 2>/tmp/env_err.txt | tail -1 > /tmp/env_line.json
     python - "$e" "$w" <<'PY'
 import json, sys
 try:

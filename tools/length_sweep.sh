@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 for w in cfg2 cfg3; do
   for L in 36 50 76 100 125 150 200 250 300; do
-    python bench.py --workload $w --read-len $L --no-also --no-cpu-baseline --no-tiers --no-traffic --steps 100 --warmup 30 2>/dev/null | tail -1 > /tmp/ls.json
+    python bench.py --workload $w --read-len $L --no-also --no-cpu-baseline --no-tiers --no-traffic --no-steady --steps 100 --warmup 30 2>/dev/null | tail -1 > /tmp/ls.json
     python - "$w" "$L" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ls.json")); r = d["roofline"]

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 export ROCPROFILER_PC_SAMPLING_BETA_ENABLED=1
 UNIT=time; [ "$METHOD" = stochastic ] && UNIT=cycles
 timeout -k 10 400 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-method $METHOD --pc-sampling-unit $UNIT --pc-sampling-interval $IVAL \
-  --kernel-trace --output-format csv json -d $OUT/run -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --no-tiers --no-traffic $* > $OUT/run.log 2>&1
+  --kernel-trace --output-format csv json -d $OUT/run -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --no-tiers --no-traffic --no-steady $* > $OUT/run.log 2>&1
 echo "rc=$?" >> $OUT/run.log
 tail -5 $OUT/run.log
 find $OUT/run -type f | head -20

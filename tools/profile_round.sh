@@ -9,10 +9,10 @@ TAG=$1; shift
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-tiers --no-traffic $*"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also --no-tiers --no-traffic --no-steady $*"
 echo "== kernel trace"
 # same step counts as the default bench line, so that the two averages are comparable
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --no-tiers --no-traffic $* > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --no-tiers --no-traffic --no-steady $* > $OUT/trace.log 2>&1
 echo "== pmc FETCH_SIZE"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 echo "== pmc WRITE_SIZE"
