@@ -92,6 +92,32 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1
 
 
+def test_bench_under_the_drivers_launcher(tmp_path):
+    """the driver's own command line for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` — here with two ranks on device 0 and a gloo
+    exchange: RANK / LOCAL_RANK / WORLD_SIZE come from the launcher; the line carries the like-for-like one-GPU
+    reference (measured on rank 0 before the group forms) and config 3's share with its own"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0",
+                        "--reads", "200000", "--steps", "3", "--warmup", "1", "--also-steps", "3", "--also-warmup", "2"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["ranks"]["world_size"] == 2
+    assert line["n1_reference"]["value"] > 0 and 0 < line["efficiency_vs_n1_reference"] < 1.5
+    share = line["also"]["cfg3_share"]
+    assert "300 bp" in share["workload"] and share["n1_reference"]["value"] > 0 and len(share["per_rank"]) == 2
+    assert "ONE all-reduce" in line["ranks"]["exchange"]
+
+
 def test_bench_fails_when_a_rank_fails():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
