@@ -197,10 +197,19 @@ constexpr uint32_t kStageReadsMax = 8192;
 constexpr uint32_t kCandCap = 96;                       // entries per wave: drained above 32, a step adds <= 64
 constexpr uint32_t kCandWords = 16u * kCandCap * 2u;    // 16 waves x 96 entries x 8 bytes = 12 KiB
 constexpr uint32_t kCandWords16 = 16u * kCandCap * 4u;  // W16 builds: one 16-byte entry per LANE (16 positions): 24 KiB
+// First hits of a fixed-length one-tile batch stay in the LDS (round 3): all lanes of a read sit in one workgroup in
+// one step, so min(first hit) needs no global memory — a ring of kFhRing words indexed by the read's place in the
+// slice, folded into the kmer_count row and cleared every G <= kFhRing / 2 reads behind a workgroup barrier (every
+// wave drains its queue in front of the barrier).  What it replaces: one global atomicMin per read with a hit — 2.9 M
+// per 10M x 300, each a random 128-byte line of a 40 MB array through the L2 and, gfx9 having ONE counter for loads
+// and atomics, inside the wait for the next step's loads — 7-10 % of the kernel, measured by leaving the atomic out;
+// plus the reset of that array before and its read-back after the loop.
+constexpr uint32_t kFhRing = 2048;
 inline size_t hist_lds_bytes(uint32_t ch, uint32_t replicas, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false,
                              uint32_t stage_reads = kStageReads, bool w16 = false) {
   return ((size_t)kQRows * hist_row_dwords(ch, replicas) + (adapt ? 6u : 5u) * 8u * ch + 4u + (adapt ? kFusedFilterWords + (w16 ? kCandWords16 : kCandWords) : 0u)) * sizeof(uint32_t) +
-         (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)stage_reads * (adapt ? 12 : 8) : 0);
+         (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)stage_reads * (adapt ? 12 : 8) : 0) +
+         (adapt && !ragged ? (size_t)kFhRing * 4 : 0);   // fixed-length batches: the first-hit ring (where a ragged batch stages its reads)
 }
 
 // The fused path works on COMPLEMENTED 2-bit codes (3 - code: the "not T / not C /
@@ -364,6 +373,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       reinterpret_cast<char *>(lds_misc + 4u) + ((ADAPT && p.bucket_log2) ? (16u << p.bucket_log2) : 0u));
   const uint32_t SR = STAGED ? p.stage_reads : kStageReads;
   uint32_t *lds_ridx = reinterpret_cast<uint32_t *>(lds_list + SR);   // ADAPT: index of a staged read within its pass
+  uint32_t *lds_fh = reinterpret_cast<uint32_t *>(lds_list);          // ADAPT, FIXED: the first-hit ring (kFhRing words)
+
   const uint64_t TL = p.table_len;
 
   if (ADAPT) {
@@ -394,6 +405,12 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   const int32_t ch_signed = (int32_t)chh - (int32_t)H;
   const uint32_t RW = p.reads_per_iter;
   const bool lane_on = lane_id >= feeders && !is_halo && ri < RW;
+  // one tile, fixed length: first hits are kept in lds_fh, see kFhRing (wave-uniform, the same for the whole launch;
+  // a step of more reads than half the ring — reads of a chunk or two — keeps the global words)
+  const bool fh_ring = ADAPT && FIXED && p.count_in_kernel != 0 && RW * (uint32_t)U <= kFhRing / 2u;
+  // reads between two folds of the ring: whole steps, at most half the ring
+  const uint32_t fh_group = fh_ring ? (kFhRing / 2u) / (RW * (uint32_t)U) * (RW * (uint32_t)U) : 0u;
+  uint32_t fh_folded = 0, fh_next = 0;   // reads of the slice whose ring entries have been folded; the next fold point (wave-uniform)
   // the lane's K chunks of the tile and their LDS columns.  W16: chunks 2*chl and 2*chl + 1; the even chunks of a
   // tile take the first CH/2 columns of a set, the odd ones the second half — the lanes of ONE counting instruction
   // (same k) then touch consecutive dwords, as they do with one chunk per lane
@@ -559,7 +576,12 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     // pass of their own before the launch and no counting kernel behind it (adapter_count_kernel) —
     // 45 us of a 1.5 ms step on 10M x 300.  Reset here, count below, both with device-coherent
     // accesses: the atomicMin of the drain happens at the memory side.
-    if (ADAPT && p.count_in_kernel) {
+    if (fh_ring) {
+      for (uint32_t i = tid; i < kFhRing; i += T) lds_fh[i] = kNoHit;
+      fh_folded = 0;
+      fh_next = fh_group;
+      __syncthreads();
+    } else if (ADAPT && p.count_in_kernel) {
       for (uint32_t i = tid; i < slice_reads; i += T)
         __hip_atomic_store(&p.first_hit[r_begin + i], kNoHit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (every access to these words is an agent-scope atomic and the barrier orders them: no __threadfence —
@@ -606,6 +628,19 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       pf0 = obase[pfid];
       pf1 = lbase ? pf0 + lbase[pfid] : obase[pfid + 1u];
     }
+    // first-hit ring -> kmer_count row, for the reads [fh_folded, upto) of the slice (every candidate of theirs has been
+    // drained: the callers drain and meet at a barrier first).  quack.c:211-217: i ends one past the first window
+    // found; counted iff i < l.
+    auto fold_first_hits = [&](uint32_t upto) {
+      for (uint32_t rel = fh_folded + tid; rel < upto; rel += T) {
+        const uint32_t v = lds_fh[rel & (kFhRing - 1u)];
+        if (v == kNoHit) continue;
+        const uint32_t len = SV ? p.lengths[(size_t)r_begin + rel] : p.read_len;
+        if (v + 1u < len && v + 1u < TP) lds_add(lds_kmer, 4u * (v + 1u), 1u);
+        lds_fh[rel & (kFhRing - 1u)] = kNoHit;
+      }
+      fh_folded = upto;
+    };
     for (uint32_t pass = 0; pass < slice_reads; pass += STAGED ? SR : slice_reads) {
       uint32_t n_list = slice_reads;   // FIXED: every read of the slice
       if (STAGED) {
@@ -810,11 +845,18 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           const uint32_t prev_rd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane_id + 63u) & 63u) << 2), (int)rd);
           const uint32_t prev_found = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane_id + 63u) & 63u) << 2), (int)found);
           const bool covered = lane_id != 0 && prev_rd == rd && prev_found <= found;
-          if (found != kNoHit && !covered) atomicMin(&p.first_hit[rd], found);
+#if defined(QK_ABL) && (QK_ABL & 64)   /* experiment: everything but the global atomic */
+          if (found != kNoHit && !covered) keep ^= found + rd;
+#else
+          if (found != kNoHit && !covered) {
+            if (fh_ring) __hip_atomic_fetch_min(&lds_fh[rel & (kFhRing - 1u)], found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else atomicMin(&p.first_hit[rd], found);
+          }
+#endif
         }
         cand_n = 0;
       };
-      auto consume = [&](const LoadT (&q)[U], const LoadT (&s)[U], const uint32_t (&nv)[U], const uint32_t (&sk)[U],
+      auto consume = [&](uint32_t it_step, const LoadT (&q)[U], const LoadT (&s)[U], const uint32_t (&nv)[U], const uint32_t (&sk)[U],
                          const uint32_t (&rl)[U]) __attribute__((always_inline)) {
       // ADAPT builds run the U reads of a step in two rounds: first the letters of every
       // read (indicators, counters, codes, the four filter probes), then the quality
@@ -824,6 +866,23 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       // cannot afford to wait for an LDS round trip per read).
       uint32_t qwU[U][K][2], ploU[U][K], bytU[U][K][4], nU[U];
       bool liveU[U];
+      // The queue is checked at the START of a step (round 3), not behind the push that filled it: the check ends in
+      // global atomics, which count against vmcnt like the loads do — gfx9 has one counter — and the next thing the loop
+      // does is wait for the loads of the coming step with vmcnt(0).  Behind the push that wait took the atomics' round
+      // trip as well (measured by leaving the atomic out: 5 % of the config-3 kernel); here they have a whole step.
+#if !(defined(QK_ABL) && (QK_ABL & 32))
+      if (fh_ring && it_step == fh_next) {
+        fh_next += fh_group;
+        // a fold point of the first-hit ring (kFhRing): every wave empties its queue, the workgroup meets, and the
+        // entries of the reads before this step go to the kmer_count row.  (The reads of THIS group write other slots
+        // — a group is at most half the ring —, and the next group starts behind the next barrier.)
+        if (cand_n) drain_candidates();
+        __syncthreads();
+        fold_first_hits(it_step);
+      } else if (ADAPT && MODE == 0 && cand_n > kCandCap - 64u) {
+        drain_candidates();
+      }
+#endif
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // bytes past the end of the read -> 0xFF: quality row 127 is discarded
@@ -934,6 +993,9 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             constexpr uint32_t kW1 = 0x01041040u, kW2 = 0x02082080u, kW3 = 0x030C30C0u, kBias = 0u - 255u;
             const uint32_t c80 = __builtin_amdgcn_udot4(ng[0], kW3, __builtin_amdgcn_udot4(nc[0], kW2, __builtin_amdgcn_udot4(nt[0], kW1, kBias, false), false), false);
             own16K[k] = __builtin_amdgcn_udot4(ng[1], kW3, __builtin_amdgcn_udot4(nc[1], kW2, __builtin_amdgcn_udot4(nt[1], kW1, (c80 << 8) + kBias, false), false), false);
+#if defined(QK_ABL) && (QK_ABL & 4)   /* experiment: no codes at all */
+            own16K[k] = 0u;
+#endif
           }
         }
         }   // k
@@ -955,7 +1017,12 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
               // chunk's eight windows.  (The filter holds both 9-mers of every adapter
               // 10-mer; it sits at LDS byte 0, so the key field is the address.)
 #pragma unroll
+#if defined(QK_ABL) && (QK_ABL & 6)   /* experiment: no filter probes */
+              for (int m = 0; m < 4; ++m) bytU[u][k][m] = 0u;
+              if (QK_ABL & 2) keep ^= plo;   /* (the codes stay alive) */
+#else
               for (int m = 0; m < 4; ++m) bytU[u][k][m] = lds_abs_u32((plo >> (2 * (7 - 2 * m) + 3)) & ((1u << (kFusedFilterLog2 - 3)) - 4u));
+#endif
             }
           }
         }
@@ -982,6 +1049,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
               const uint32_t wr = __builtin_amdgcn_alignbit(qwU[u][k][jj], qwU[u][k][jj], rot8);
+#if defined(QK_ABL) && (QK_ABL & 1)   /* experiment: no quality atomics (addresses still computed) */
+              keep ^= ((wr & 0x7Fu) << 7 | qcol[k][0]) ^ (((wr >> 1) & mask7) | qcol[k][1]) ^ (((wr >> 9) & mask7) | qcol[k][2]) ^ (((wr >> 17) & mask7) | qcol[k][3]);
+              continue;
+#endif
               qhist_add<0, kHistBase>(wr, mask7, qcol[k][0], jj ? one_hi : one_lo);
               qhist_add<1, kHistBase>(wr, mask7, qcol[k][1], jj ? one_hi : one_lo);
               qhist_add<2, kHistBase>(wr, mask7, qcol[k][2], jj ? one_hi : one_lo);
@@ -1007,6 +1078,17 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           }
           // lanes that count nothing (feeders, halo, past the end) have no windows
           hits = n ? hits : 0u;
+#if defined(QK_ABL) && (QK_ABL & 6)
+          hits = 0u;
+#endif
+#if defined(QK_ABL) && (QK_ABL & 8)    /* experiment: probes issued, answers unused */
+          keep ^= bytU[u][0][0] ^ bytU[u][0][1] ^ bytU[u][0][2] ^ bytU[u][0][3] ^ bytU[u][K - 1][0] ^ bytU[u][K - 1][1] ^ bytU[u][K - 1][2] ^ bytU[u][K - 1][3];
+          hits = 0u;
+#endif
+#if defined(QK_ABL) && (QK_ABL & 16)   /* experiment: probes and answers, nobody queues */
+          keep ^= hits;
+          hits = 0u;
+#endif
           const uint64_t pushers = __builtin_amdgcn_ballot_w64(hits != 0u);
           if (pushers) {   // (wave-uniform)
             // position cpos-9: the last base of the chunk two chunks back — the previous lane's (W16: its first chunk)
@@ -1019,7 +1101,12 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
                 cand_q[at] = make_uint2(ploU[u][0], prev2 | (hits << 2) | lane10 | (rl[u] << 16));
             }
             cand_n += (uint32_t)__builtin_popcountll(pushers);
-            if (cand_n > kCandCap - 64u) drain_candidates();
+#if defined(QK_ABL) && (QK_ABL & 32)   /* experiment: candidates queued, never checked */
+            if (cand_n > kCandCap - 64u) cand_n = 0;
+#else
+            // (room for the next read's entries; behind the last read of a step the check at the start of the next one does)
+            if (u + 1 < U && cand_n > kCandCap - 64u) drain_candidates();
+#endif
           }
         }
       }
@@ -1040,7 +1127,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           for (int d = 0; d < PD; ++d) {
             const int nx = (d + PD - 1) % PD;
             issue(it + (uint32_t)(d + PD - 1) * RW * U, q[nx], s[nx], nv[nx], sk[nx], rl[nx]);
-            if (d == 0 || it + (uint32_t)d * RW * U < n_list) consume(q[d], s[d], nv[d], sk[d], rl[d]);
+            if (d == 0 || it + (uint32_t)d * RW * U < n_list) consume(it + (uint32_t)d * RW * U, q[d], s[d], nv[d], sk[d], rl[d]);
           }
         }
       } else {
@@ -1050,12 +1137,17 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           uint32_t nv[U], sk[U], rl[U];
           issue(it, q, s, nv, sk, rl);
           if (STAGED) load_desc(it + RW * U);
-          consume(q, s, nv, sk, rl);
+          consume(it, q, s, nv, sk, rl);
         }
       }
+#if !(defined(QK_ABL) && (QK_ABL & 32))
       if (ADAPT && cand_n) drain_candidates();   // the entries refer to this pass's read list
+#endif
     }
-    if (ADAPT && p.count_in_kernel) {
+    if (fh_ring) {
+      __syncthreads();   // every wave has drained its queue (above)
+      fold_first_hits(slice_reads);
+    } else if (ADAPT && p.count_in_kernel) {
       // quack.c:211-217: i ends one past the first window found; counted iff i < l
       __syncthreads();
       // (eight loads in flight per thread: they bypass the caches, and one round trip per read — 38 in a row
@@ -1194,7 +1286,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   if (MODE == 1) {
     if (keep == 0x12345678u) lds[0] = keep;
   }
-#ifdef QK_DUMMY_VALU
+#if defined(QK_DUMMY_VALU) || defined(QK_ABL)
   if (keep == 0x12345679u) lds[1] = keep;
 #endif
   if (cur_tile != 0xFFFFFFFFu) flush(cur_tile);
