@@ -1372,9 +1372,10 @@ __global__ __launch_bounds__(kReachThreads) void reach_count_kernel(const HistPa
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < nb; i += kReachThreads)
     if (lc[i]) atomicAdd(&counts[i], lc[i]);
-  __threadfence();
+  // (the barrier waits for the atomics; the ticket's release orders them for the last block.  A __threadfence() by every
+  // thread here was most of this kernel's 15 us: an agent-scope fence writes back and invalidates the XCD's L2)
   __syncthreads();
-  if (threadIdx.x == 0) lc[nb] = atomicAdd(done, 1u);
+  if (threadIdx.x == 0) lc[nb] = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (lc[nb] != gridDim.x - 1u) return;
   // last block: every other block's counts are in (their atomics precede their ticket)

@@ -92,6 +92,9 @@ struct TimedLaunch {
 
 }  // namespace
 
+constexpr int kSets = 2;   // order / reach buffer sets: the pre-pass of batch k + 1 runs while the histogram kernel of batch k reads its own
+                           // (a third set, so that no pre-pass starts together with a histogram kernel: measured, no difference)
+
 struct qk_accum {
   int device = 0;
   int n_cu = 256;
@@ -126,9 +129,9 @@ struct qk_accum {
   // long ragged reads: reads ordered by the tiles they reach (qk::reach_* kernels)
   // (two sets, used in turn: the pre-pass of batch k+1 may run — on the side stream below — while the histogram
   // kernel of batch k still reads its own)
-  uint32_t *d_order[2] = {nullptr, nullptr};        // [order_cap]
-  uint64_t order_cap[2] = {0, 0};
-  uint32_t *d_reach[2] = {nullptr, nullptr};        // [kReachMaxTiles] reach | [kReachMaxTiles + 1] counts | [kReachMaxTiles + 1] cursor
+  uint32_t *d_order[kSets] = {};       // [order_cap]
+  uint64_t order_cap[kSets] = {};
+  uint32_t *d_reach[kSets] = {};       // [kReachMaxTiles] reach | [kReachMaxTiles + 1] counts | [kReachMaxTiles + 1] cursor
   unsigned set_turn = 0;
   // Side stream (round 3): the reach sort of long ragged reads, which only reads the batch's lengths, runs here when
   // the batch was submitted on the accumulator's OWN stream
@@ -140,8 +143,8 @@ struct qk_accum {
   // stream (their copies come first, and the two slots overlap each other anyway).
   hipStream_t side = nullptr;
   hipEvent_t side_done = nullptr;                   // behind a pre-pass on `side`: the histogram kernel waits for it
-  hipEvent_t set_free[2] = {nullptr, nullptr};      // behind the histogram kernel that read set i
-  bool set_busy[2] = {false, false};
+  hipEvent_t set_free[kSets] = {};     // behind the histogram kernel that read set i
+  bool set_busy[kSets] = {};
   uint32_t *d_status = nullptr;       // device word: bit 0 = an "aligned" batch was not aligned
   bool status_armed = false;
   hipEvent_t order_ev = nullptr;
@@ -676,7 +679,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     hp.lengths_done = 1;
   }
   if (pl.sorted) {
-    set = (int)(a->set_turn++ & 1u);
+    set = (int)(a->set_turn++ % (unsigned)kSets);
     if (a->order_cap[set] < n_reads) {
       QK_HIP(hipDeviceSynchronize());
       if (a->d_order[set]) QK_HIP(hipFree(a->d_order[set]));
@@ -694,11 +697,11 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     uint32_t *reach = a->d_reach[set], *counts = reach + qk::kReachMaxTiles, *cursor = counts + qk::kReachMaxTiles + 1;
     uint32_t *done = cursor + qk::kReachMaxTiles + 1;
     unsigned long long *prefix = reinterpret_cast<unsigned long long *>(reach + 3 * (size_t)qk::kReachMaxTiles + 4);
+    // the set's previous user — the histogram kernel of two batches ago — must have finished with it
+    if (a->set_busy[set]) QK_HIP(hipStreamWaitEvent(pre, a->set_free[set], 0));
     const size_t lds = (pl.n_tiles + 2) * sizeof(uint32_t);
     // few blocks: every block costs one same-address atomic per bucket (~15 ns each, serialised)
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_reads / 1024, (uint64_t)a->n_cu * 4));
-    // the set's previous user — the histogram kernel of two batches ago — must have finished with it
-    if (a->set_busy[set]) QK_HIP(hipStreamWaitEvent(pre, a->set_free[set], 0));
     hipLaunchKernelGGL(qk::reach_count_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, pre, hp, counts, done, reach, cursor, prefix);
     hipLaunchKernelGGL(qk::reach_scatter_kernel, dim3(blocks), dim3(qk::kReachThreads), lds, pre, hp, cursor, a->d_order[set]);
     QK_HIP(hipGetLastError());
@@ -1076,7 +1079,7 @@ void qk_accum_destroy(qk_accum *a) {
   for (auto e : a->event_pool) (void)hipEventDestroy(e);
   if (a->d_queues) (void)hipFree(a->d_queues);
   if (a->d_status) (void)hipFree(a->d_status);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kSets; ++i) {
     if (a->d_order[i]) (void)hipFree(a->d_order[i]);
     if (a->d_reach[i]) (void)hipFree(a->d_reach[i]);
     if (a->set_free[i]) (void)hipEventDestroy(a->set_free[i]);

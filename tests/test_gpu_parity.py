@@ -865,11 +865,13 @@ def test_host_feed_lays_trimmed_reads_out_at_a_fixed_stride(tmp_path, monkeypatc
 
 # ---------------------------------------------------------------- long ragged reads: reach sort + static split
 @pytest.mark.parametrize("n,lo,hi,adapters", [(50, 1000, 20000, False), (300, 5000, 5000, False), (3000, 0, 9000, True),
-                                              (700, 2049, 2049, False), (40000, 1500, 3000, False), (257, 511, 40000, True)])
+                                              (700, 2049, 2049, False), (40000, 1500, 3000, False), (257, 511, 40000, True),
+                                              (300000, 600, 2600, False)])
 def test_long_ragged_reads_static_split(n, lo, hi, adapters):
     """4..64 tiles: the reads are sorted by reach and the read-tiles are cut into one share per workgroup —
     fewer reads than workgroups, equal lengths (every tile the same work), zero-length reads in between,
-    a length one past a tile boundary, more reads than one item may hold, packed and on cache lines"""
+    a length one past a tile boundary, more reads than one item may hold, more reads than the pre-pass has
+    threads, packed and on cache lines"""
     import torch
     ads = synth.synthetic_adapters()
     k = ob.kmers_from_seqs(ads) if adapters else None
