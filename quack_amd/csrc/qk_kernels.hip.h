@@ -101,6 +101,7 @@ struct HistParams {
   // takes the b-th of gridDim.x equal, contiguous shares of the read-tiles
   const unsigned long long *tile_prefix;   // [n_tiles + 1] reads of the tiles before t, or NULL (t * n_reads)
   uint32_t static_split;
+  uint32_t tile_overhead;       // static split: what a tile costs a workgroup besides its reads (the flush), in read-tiles
   uint32_t no_adapters;         // kmers == NULL semantics (quack.c:210,215)
   uint32_t count_in_kernel;     // fused adapters, one tile: hist_kernel resets first_hit[] and takes the kmer_count itself
   // exact LDS-resident membership table the queued candidates are checked against (0: the
@@ -1197,11 +1198,16 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     // one and the head of the next — one or two histograms to flush, no queue, no atomics, and as
     // few items as there can be (per-item costs — staging latency, barriers, the flush — were a
     // tenth of the long-read kernel: 1-20 kb reads 0.63 -> 0.55 ms).
-    auto prefix = [&](uint32_t t) -> uint64_t { return p.tile_prefix ? p.tile_prefix[t] : (uint64_t)t * p.n_reads; };
+    // A tile a share touches costs its workgroup a flush whatever the number of reads (40 quality rows x 512 positions of
+    // u64 atomics: ~16 us, the time of ~300 read-tiles), and the last workgroups cross two or three of the thinly
+    // populated far tiles: every tile is therefore `tile_overhead` items longer than its reads — items in front of the
+    // reads that stand for the flush and are never run.
+    const uint64_t F = p.tile_overhead;
+    auto prefix = [&](uint32_t t) -> uint64_t { return (p.tile_prefix ? p.tile_prefix[t] : (uint64_t)t * p.n_reads) + (uint64_t)t * F; };
     const uint64_t W = prefix(p.n_tiles);
     uint64_t lo = W / gridDim.x * blockIdx.x + (W % gridDim.x) * blockIdx.x / gridDim.x;
     const uint64_t hi = blockIdx.x + 1u == gridDim.x ? W : W / gridDim.x * (blockIdx.x + 1u) + (W % gridDim.x) * (blockIdx.x + 1u) / gridDim.x;
-    // the tile that holds read-tile `lo`: the last t with prefix(t) <= lo
+    // the tile that holds item `lo`: the last t with prefix(t) <= lo
     uint32_t ta = 0, tb = p.n_tiles;   // invariant: prefix(ta) <= lo < prefix(tb) (when lo < W)
     while (tb - ta > 1u) {
       const uint32_t mid = (ta + tb) / 2u;
@@ -1209,16 +1215,17 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       else tb = mid;
     }
     for (uint32_t t = ta; lo < hi && t < p.n_tiles; ++t) {
-      const uint64_t t0 = prefix(t), t1 = prefix(t + 1u);
+      const uint64_t t0 = prefix(t) + F, t1 = prefix(t + 1u);   // the tile's reads are items [t0, t1)
       const uint64_t seg_hi = hi < t1 ? hi : t1;
-      if (seg_hi > lo) {
+      const uint64_t seg_lo = lo > t0 ? lo : t0;
+      if (seg_hi > seg_lo) {
         // (items of at most reads_per_slice reads: the u16 counters of a histogram)
-        for (uint64_t r = lo - t0; r < seg_hi - t0; r += p.reads_per_slice) {
+        for (uint64_t r = seg_lo - t0; r < seg_hi - t0; r += p.reads_per_slice) {
           const uint64_t e = r + p.reads_per_slice < seg_hi - t0 ? r + p.reads_per_slice : seg_hi - t0;
           run_item(t, r, e);
         }
-        lo = seg_hi;
       }
+      if (seg_hi > lo) lo = seg_hi;
     }
   } else
   if (p.queue == nullptr) {

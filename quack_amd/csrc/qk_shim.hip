@@ -608,7 +608,10 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     tl.b1 = tl.t1;
     // batches with a pre-pass (queue reset, reach sort, length kernel) or an adapter
     // count kernel get their own pair of events around the whole batch
-    if (pl.n_tiles > 1 || a->adapters || strided) {
+    // (not a fused one-tile adapter batch: the histogram kernel is all of it, and two more events would add their own
+    // ~10 us of stream time to what they measure)
+    const bool one_kernel = pl.fused_adapters && pl.n_tiles == 1 && !getenv("QUACK_HIP_SEPARATE_COUNT");
+    if (pl.n_tiles > 1 || (a->adapters && !one_kernel) || strided) {
       tl.b0 = get_event(a);
       tl.b1 = get_event(a);
       if (!tl.b0 || !tl.b1) return fail(QK_EHIP, "hipEventCreate failed");
@@ -721,6 +724,10 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   // 3000 x 100-500 kb 1.18 vs 0.95; up to there static wins: 300k x 0.1-5 kb 0.355 vs 0.410, config 5.)
   if (static_split) {
     hp.static_split = 1;
+    // what crossing into another tile costs a workgroup (clearing and flushing a histogram), in read-tiles: measured on
+    // 1-20 kb reads inside one process (tools/ab_inproc.py): 0 -> 0.5822 ms, 150 0.5812, 300 0.5738, 450 0.5746,
+    // 600 0.5737, 900 0.5755, 1200 0.5766, 2400 0.5815, 4800 0.5835
+    hp.tile_overhead = (uint32_t)std::max(0, env_int("QUACK_HIP_TILE_OVERHEAD", 400));
     const uint64_t step = (uint64_t)pl.rw * (uint32_t)pl.unroll;
     hp.reads_per_slice = (qk::kMaxReadsPerSlice - step) / step * step;
   }
