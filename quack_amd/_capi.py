@@ -48,7 +48,13 @@ def hip():
     global _hip
     if _hip is not None:
         return _hip
-    L = _load("libquack_hip.so")
+    _hip = bind_hip(_load("libquack_hip.so"))
+    return _hip
+
+
+def bind_hip(L):
+    """argtypes of every symbol of include/quack_hip.h on a loaded library (hip() does this for the product's own;
+    tools/ab_inproc.py binds a second build beside it)"""
     L.qk_last_error.restype = ctypes.c_char_p
     L.qk_version.restype = ctypes.c_char_p
     L.qk_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
@@ -84,7 +90,6 @@ def hip():
     L.qk_accum_timing_read_batch.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_u64p]
     L.qk_accum_timing_read_range.argtypes = [c_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     L.qk_accum_configure.argtypes = [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-    _hip = L
     return L
 
 

@@ -112,9 +112,9 @@ class Accumulator:
     one GPU.  Host batches are numpy arrays; device batches are anything with
     a data_ptr() (torch tensors on the accumulator's device)."""
 
-    def __init__(self, device=0, kmers=None, max_len_hint=0):
+    def __init__(self, device=0, kmers=None, max_len_hint=0, _lib=None):
         self._h = ctypes.c_void_p()
-        self._L = _capi.hip()
+        self._L = _lib if _lib is not None else _capi.hip()   # (_lib: a second build bound with _capi.bind_hip, developer tools only)
         kp = kmers.ctypes.data if kmers is not None else None
         self._kmers = kmers  # keep alive during create
         _check(self._L.qk_accum_create(ctypes.byref(self._h), device, kp, max_len_hint))

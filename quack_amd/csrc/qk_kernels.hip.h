@@ -411,7 +411,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   const bool fh_ring = ADAPT && FIXED && p.count_in_kernel != 0 && RW * (uint32_t)U <= kFhRing / 2u;
   // reads between two folds of the ring: whole steps, at most half the ring
   const uint32_t fh_group = fh_ring ? (kFhRing / 2u) / (RW * (uint32_t)U) * (RW * (uint32_t)U) : 0u;
-  uint32_t fh_folded = 0, fh_next = 0;   // reads of the slice whose ring entries have been folded; the next fold point (wave-uniform)
+  constexpr bool kScalarLoop = W16 && ADAPT && FIXED;   // see the step loop
+  uint32_t fh_folded = 0, fh_next = 0xFFFFFFFFu;   // reads of the slice whose ring entries have been folded; the next fold point (wave-uniform)
   // the lane's K chunks of the tile and their LDS columns.  W16: chunks 2*chl and 2*chl + 1; the even chunks of a
   // tile take the first CH/2 columns of a set, the odd ones the second half — the lanes of ONE counting instruction
   // (same k) then touch consecutive dwords, as they do with one chunk per lane
@@ -872,7 +873,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       // does is wait for the loads of the coming step with vmcnt(0).  Behind the push that wait took the atomics' round
       // trip as well (measured by leaving the atomic out: 5 % of the config-3 kernel); here they have a whole step.
 #if !(defined(QK_ABL) && (QK_ABL & 32))
-      if (fh_ring && it_step == fh_next) {
+      if ((kScalarLoop || fh_ring) && it_step == fh_next) {   // (kScalarLoop: without the ring no step has fh_next's index)
         fh_next += fh_group;
         // a fold point of the first-hit ring (kFhRing): every wave empties its queue, the workgroup meets, and the
         // entries of the reads before this step go to the kmer_count row.  (The reads of THIS group write other slots
@@ -1123,6 +1124,29 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         uint32_t nv[PD][U], sk[PD][U], rl[PD][U];
 #pragma unroll
         for (int d = 0; d < PD - 1; ++d) issue((uint32_t)d * RW * U, q[d], s[d], nv[d], sk[d], rl[d]);
+        if constexpr (kScalarLoop) {
+          // The VALU-bound variant (fixed-length reads with the adapter scan, 16 positions per lane) gets its loop
+          // bookkeeping off the VALU: the list length comes out of a ticket, so the compiler kept the step counter in a
+          // VGPR (compare, add, v_readfirstlane per step) — told to be uniform, it lives in an SGPR; and it kept 2 * RW * U
+          // in a register and RE-READ RW from the kernel arguments in every step, with an s_waitcnt lgkmcnt(0) that also
+          // waits for the previous step's LDS atomics — one opaque increment serves both counters.  -1.4 % on config 3
+          // measured inside one process (tools/ab_inproc.py); the other variants showed nothing and keep the plain loop
+          // (some spill more with this one).
+          const uint32_t n_steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_list);
+          uint32_t step_reads = RW * (uint32_t)U;
+          asm volatile("" : "+s"(step_reads));
+          uint32_t it = 0, ahead = (uint32_t)(PD - 1) * step_reads;
+          while (it < n_steps) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+              const int nx = (d + PD - 1) % PD;
+              issue(ahead, q[nx], s[nx], nv[nx], sk[nx], rl[nx]);
+              ahead += step_reads;
+              if (d == 0 || it < n_steps) consume(it, q[d], s[d], nv[d], sk[d], rl[d]);
+              it += step_reads;
+            }
+          }
+        } else
         for (uint32_t it = 0; it < n_list; it += (uint32_t)PD * RW * U) {
 #pragma unroll
           for (int d = 0; d < PD; ++d) {

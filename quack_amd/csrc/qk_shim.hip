@@ -1084,6 +1084,9 @@ void qk_accum_destroy(qk_accum *a) {
     }
   }
   for (auto e : a->event_pool) (void)hipEventDestroy(e);
+  if (getenv("QUACK_HIP_DEBUG_ADDR"))   // (where this accumulator's buffers lay: tools/ab_inproc.py --addresses)
+    fprintf(stderr, "quack_hip: acc table %p order %p %p reach %p %p queues %p stream %p side %p\n", (void *)a->d_table, (void *)a->d_order[0],
+            (void *)a->d_order[1], (void *)a->d_reach[0], (void *)a->d_reach[1], (void *)a->d_queues, (void *)a->stream, (void *)a->side);
   if (a->d_queues) (void)hipFree(a->d_queues);
   if (a->d_status) (void)hipFree(a->d_status);
   for (int i = 0; i < kSets; ++i) {

@@ -1,9 +1,12 @@
 """Two (or more) environment settings of the shim compared INSIDE one process, alternating every few launches —
 the boxes drift between two states for seconds at a time (profiles/r03_ab_prepass.log), which process-level
-alternation (env_abc.sh) only averages out over many rounds.  Works for every knob the shim reads per submit.
-   python tools/ab_inproc.py [--block 10] [--rounds 30] <workload> - "QUACK_HIP_X=1" "QUACK_HIP_X=2 QUACK_HIP_Y=3"      (- = no variables)
-Prints, per setting: mean / median of the per-launch histogram-kernel time and of the whole batch (HIP events)."""
+alternation (env_abc.sh) only averages out over many rounds.  One accumulator per setting, created and fed under
+that setting's variables; LIB=<path> as a "variable" sends the setting's launches through another build of the shim.
+   python tools/ab_inproc.py [--block 10] [--rounds 30] <workload> - "QUACK_HIP_X=1" "LIB=tools/exp/e2.so QUACK_HIP_Y=3"   (- = nothing set)
+Prints, per setting: mean / median of the per-launch histogram-kernel time and of the whole batch (HIP events), and
+checks that every setting ended with the same counters."""
 import argparse
+import ctypes
 import os
 import sys
 
@@ -28,27 +31,58 @@ def main():
     ads_bits, ads = bench.synthetic_adapter_bits(np) if w["adapters"] else (None, None)
     b = bench.make_batch(torch, np, w, seed={"cfg3": 3, "cfg5": 6, "trimmed": 7}.get(a.workload, 2), device="cuda:0", quality="uniform", ads=ads)
     job = bench.Job.__new__(bench.Job)
-    keys = sorted({kv.split("=")[0] for s in settings for kv in s.split()})
+    keys = sorted({kv.split("=")[0] for s in settings for kv in s.split()} - {"LIB"})
+    libs = {}
+
+    def enter(s):
+        """the environment of setting s; -> the library its launches go through (LIB=<path>: another build of the shim,
+        loaded beside the product's with its own symbols first)"""
+        for k in keys:
+            os.environ.pop(k, None)
+        lib = None
+        for kv in s.split():
+            k, v = kv.split("=", 1)
+            if k == "LIB":
+                if v not in libs:
+                    from quack_amd import _capi
+                    libs[v] = _capi.bind_hip(ctypes.CDLL(os.path.abspath(v), mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND))
+                lib = libs[v]
+            else:
+                os.environ[k] = v
+        return lib
+
     res = {s: ([], []) for s in settings}
-    with quack_amd.Accumulator(0, ads_bits, max_len_hint=b["max_len"]) as acc:
-        for _ in range(a.warm):
-            bench.Job.submit(job, acc, b, None)
-        acc.sync()
-        for r in range(a.rounds):
-            for s in (settings if r % 2 == 0 else settings[::-1]):
-                for k in keys:
-                    os.environ.pop(k, None)
-                for kv in s.split():
-                    k, v = kv.split("=")
-                    os.environ[k] = v
-                acc.timing(1)
-                for _ in range(a.block):
-                    bench.Job.submit(job, acc, b, None)
-                acc.sync()
-                k_ms, b_ms, n = acc.timing_read_batch()
-                res[s][0].append(k_ms / n)
-                res[s][1].append(b_ms / n)
-        acc.finish()
+    accs = {}
+    for s in settings:   # one accumulator per setting, created under it (some knobs are read at creation)
+        lib = enter(s)
+        accs[s] = quack_amd.Accumulator(0, ads_bits, max_len_hint=b["max_len"], _lib=lib)
+    for s in settings:
+        enter(s)
+        for _ in range(a.warm // len(settings) + 1):
+            bench.Job.submit(job, accs[s], b, None)
+        accs[s].sync()
+    for r in range(a.rounds):
+        for s in (settings if r % 2 == 0 else settings[::-1]):
+            enter(s)
+            acc = accs[s]
+            acc.timing(1)
+            for _ in range(a.block):
+                bench.Job.submit(job, acc, b, None)
+            acc.sync()
+            k_ms, b_ms, n = acc.timing_read_batch()
+            res[s][0].append(k_ms / n)
+            res[s][1].append(b_ms / n)
+    tables = {}
+    for s in settings:
+        enter(s)
+        sd = accs[s].finish()
+        tables[s] = (sd.bases.copy(), sd.number_of_sequences)
+        accs[s].close()
+    first = tables[settings[0]]
+    for s in settings[1:]:   # every setting saw the same batches the same number of times
+        same = tables[s][1] == first[1] and tables[s][0].shape == first[0].shape and bool((tables[s][0] == first[0]).all())
+        if not same:
+            print("!! the counters of %r differ from those of %r" % (s, settings[0]))
     for s in settings:
         k, bb = sorted(res[s][0]), sorted(res[s][1])
         print("%-44s blocks %3d x %d  kernel mean %.4f median %.4f min %.4f | batch mean %.4f median %.4f ms"
