@@ -803,7 +803,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       // Exact check of the queued candidates {plo, prev2 | hits << 2 | lane << 10 | rel << 16}, one entry per
       // lane.  Position and length of the chunk come back from the lane that queued it (ds_bpermute)
       // and from the read's descriptor: the queue never outlives its pass.
-      // W16: {own32, prev2 << 16 | prev16, probe bits << 24 | lane << 16, rel} — one entry per LANE, 16 windows.
+      // W16: {own32, the previous lane's code word (bits 0-15: the 8 positions before the lane's, 16-17: the one before
+      // those), probe bits << 24 | lane << 16, rel} — one entry per LANE, 16 windows.
       auto drain_candidates = [&]() {
         constexpr uint32_t NW = 8u * K;                 // windows per entry
         constexpr uint32_t kAll = (1u << NW) - 1u;
@@ -820,7 +821,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             x = (x | (x << 1)) & 0x5555u;
             hits = x * 3u;
             s_lo = e.x;
-            s_hi = e.y;
+            s_hi = e.y & 0x3FFFFu;
           } else {
             const uint2 e = cand_q[i < cand_n ? i : 0u];
             src = (e.y >> 10) & 63u;
@@ -882,7 +883,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       // issued ahead of the step's 8*U ds_adds and have long returned when they are
       // looked at (the kernel issues VALU work back to back on four waves per SIMD and
       // cannot afford to wait for an LDS round trip per read).
-      uint32_t qwU[U][K][2], ploU[U][K], bytU[U][K][4], nU[U];
+      uint32_t qwU[U][K][2], ploU[U][K], bytU[U][K][4], nU[U], prevU[U];
       bool liveU[U];
       // The queue is checked at the START of a step (round 3), not behind the push that filled it: the check ends in
       // global atomics, which count against vmcnt like the loads do — gfx9 has one counter — and the next thing the loop
@@ -1021,11 +1022,15 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           if (FAST_FIXED && count_me) steps_v += 1u;
           if (!FAST_FIXED) events += 1u;
           if (ADAPT) {
+            // W16: what travels from the previous lane is its whole second code word — first chunk in the upper half,
+            // second chunk in the lower: the lower half is the 8 positions in front of this lane, bits 16-17 the position
+            // before those (a queue entry wants both, and used to fetch the second one with a DPP of its own)
+            if constexpr (W16) prevU[u] = from_prev_lane((own16K[0] << 16) | own16K[K - 1]);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
               // the 8 positions in front of the chunk: the previous lane's last chunk (DPP), or this lane's own
               // chunk before it
-              const uint32_t prev16 = k == 0 ? from_prev_lane(own16K[K - 1]) : own16K[k - 1];
+              const uint32_t prev16 = k == 0 ? (W16 ? prevU[u] : from_prev_lane(own16K[K - 1])) : own16K[k - 1];
               const uint32_t plo = (prev16 << 16) | own16K[k];
               ploU[u][k] = plo;
               // The 9-mer that ends at owned position j is bits [2*(7-j), 2*(7-j)+18)
@@ -1126,11 +1131,12 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           const uint64_t pushers = __builtin_amdgcn_ballot_w64(hits != 0u);
           if (pushers) {   // (wave-uniform)
             // position cpos-9: the last base of the chunk two chunks back — the previous lane's (W16: its first chunk)
-            const uint32_t prev2 = from_prev_lane(W16 ? ploU[u][0] : (ploU[u][0] >> 16)) & 3u;
+            uint32_t prev2 = 0;
+            if constexpr (!W16) prev2 = from_prev_lane(ploU[u][0] >> 16) & 3u;
             if (hits) {
               const uint32_t at = cand_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushers, 0u));
-              if constexpr (W16)
-                cand_q16[at] = make_uint4((ploU[u][0] << 16) | (ploU[u][1] & 0xFFFFu), (prev2 << 16) | (ploU[u][0] >> 16), hits | (lane_id << 16), rl[u]);
+              if constexpr (W16)   // (the words as they stand: own 16 codes; the previous lane's word, of which the drain reads bits 0-17)
+                cand_q16[at] = make_uint4(ploU[u][1], prevU[u], hits | (lane_id << 16), rl[u]);
               else
                 cand_q[at] = make_uint2(ploU[u][0], prev2 | (hits << 2) | lane10 | (rl[u] << 16));
             }
