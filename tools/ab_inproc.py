@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--block", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--warm", type=int, default=80)
+    ap.add_argument("--dummy-streams", type=int, default=0, help="streams created (and kept) before the first accumulator")
+    ap.add_argument("--dummy-mb", type=int, default=0, help="device memory allocated (and kept) before the first accumulator")
     ap.add_argument("settings", nargs="*")
     a = ap.parse_args()
     settings = [("" if s == "-" else s) for s in a.settings] or ["", ""]
@@ -53,6 +55,8 @@ def main():
 
     res = {s: ([], []) for s in settings}
     accs = {}
+    dummies = [torch.cuda.Stream() for _ in range(a.dummy_streams)]
+    ballast = torch.empty(a.dummy_mb << 20, dtype=torch.uint8, device="cuda") if a.dummy_mb else None
     for s in settings:   # one accumulator per setting, created under it (some knobs are read at creation)
         lib = enter(s)
         accs[s] = quack_amd.Accumulator(0, ads_bits, max_len_hint=b["max_len"], _lib=lib)
