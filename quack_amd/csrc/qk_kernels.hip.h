@@ -80,6 +80,11 @@ struct HistParams {
   uint32_t len_limit;           // strided batches: the longest read the caller declared (lengths[] on the device are
                                 //   checked against it by the length kernels; 0: nothing to check)
   unsigned long long *table;    // planar [kOutRows][table_len]
+  uint32_t *table32;            // the same layout in 32-bit words, or NULL: what hist_kernel's flush adds to (quality and content
+                                //   rows) — the L2's atomic units take ~1.5 TB/s of ADDED BYTES chip-wide (tools/atomic_rate.hip:
+                                //   40 rows x 512 positions per workgroup, 28.5 us as u64, 12.9 us as u32), and a long-read workgroup
+                                //   spends 6 % of its time there.  The host folds it into `table` before anyone reads that, and before
+                                //   4 G reads could have gone into it.
   uint32_t *first_hit;          // per-read first adapter hit (ADAPT only)
   const uint32_t *kmer_bits;    // 2^20-bit exact table (ADAPT only)
   const uint32_t *kmer_filter;  // [2^18 bits: suffix 9-mers (separate scan kernel) | 2^18 bits: the fused path's filter, copied into LDS]
@@ -524,8 +529,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           c += (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
         }
         const uint32_t pos = P0 + pp;
-        if (c != 0 && pos < pos_limit)
-          atomicAdd(&p.table[(uint64_t)(row - 33u) * TL + pos], (unsigned long long)c);
+        if (c != 0 && pos < pos_limit) {
+          if (p.table32) atomicAdd(&p.table32[(uint64_t)(row - 33u) * TL + pos], c);
+          else atomicAdd(&p.table[(uint64_t)(row - 33u) * TL + pos], (unsigned long long)c);
+        }
       }
     }
     for (uint32_t pp = tid; pp < TP; pp += T) {
@@ -533,12 +540,20 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       const uint32_t pos = P0 + pp;
       if (v == 0 || pos >= pos_limit) continue;
       const uint32_t t = lds_base[TP + pp], c = lds_base[2u * TP + pp], g = lds_base[3u * TP + pp];
-      unsigned long long *row0 = &p.table[(uint64_t)kRowContent * TL + pos];
       const uint32_t a = v - t - c - g;                     // content[] order: A,T,C,G (quack.c:150)
-      if (a) atomicAdd(row0, (unsigned long long)a);
-      if (t) atomicAdd(row0 + TL, (unsigned long long)t);
-      if (c) atomicAdd(row0 + 2u * TL, (unsigned long long)c);
-      if (g) atomicAdd(row0 + 3u * TL, (unsigned long long)g);
+      if (p.table32) {
+        uint32_t *row0 = &p.table32[(uint64_t)kRowContent * TL + pos];
+        if (a) atomicAdd(row0, a);
+        if (t) atomicAdd(row0 + TL, t);
+        if (c) atomicAdd(row0 + 2u * TL, c);
+        if (g) atomicAdd(row0 + 3u * TL, g);
+      } else {
+        unsigned long long *row0 = &p.table[(uint64_t)kRowContent * TL + pos];
+        if (a) atomicAdd(row0, (unsigned long long)a);
+        if (t) atomicAdd(row0 + TL, (unsigned long long)t);
+        if (c) atomicAdd(row0 + 2u * TL, (unsigned long long)c);
+        if (g) atomicAdd(row0 + 3u * TL, (unsigned long long)g);
+      }
     }
     if (!FAST_FIXED && !p.lengths_done) {
       // reads that END in this tile (staged once per tile they reach, so each read counts exactly once)
@@ -1642,6 +1657,17 @@ __global__ __launch_bounds__(256) void strided_starts_kernel(unsigned long long 
     bad |= lengths[i] > len_limit;
   }
   if (bad) atomicOr(status, kStatusBadLength);
+}
+
+// table += table32, table32 = 0 (HistParams::table32)
+__global__ __launch_bounds__(256) void table_fold_kernel(unsigned long long *table, uint32_t *table32, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const uint32_t v = table32[i];
+    if (v) {
+      table[i] += v;
+      table32[i] = 0;
+    }
+  }
 }
 
 // dst += src over the planar tables of two accumulators on the same device

@@ -100,6 +100,8 @@ struct qk_accum {
   int n_cu = 256;
   // counter table: planar [QK_N_ROWS][table_len] u64 + 1 trailing word
   unsigned long long *d_table = nullptr;
+  uint32_t *d_table32 = nullptr;      // what the histogram kernels flush into (qk::HistParams::table32); folded into d_table by settle()
+  uint64_t reads32 = 0;               // reads that may have been counted into d_table32 since it was last folded
   uint64_t table_len = 0;
   uint64_t max_len = 0;
   uint64_t n_reads = 0;
@@ -198,9 +200,26 @@ int ensure_slot(qk_accum *a, int i) {
 
 // Grow the planar table so that it holds `need` positions.  Rare (once or
 // twice per file, like the realloc at quack.c:194-198), so it synchronises.
+int fold_table32(qk_accum *a, hipStream_t st) {
+  if (!a->d_table32 || a->reads32 == 0) return QK_OK;
+  const size_t n = (size_t)QK_N_ROWS * a->table_len;
+  hipLaunchKernelGGL(qk::table_fold_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, a->d_table,
+                     a->d_table32, n);
+  QK_HIP(hipGetLastError());
+  a->reads32 = 0;
+  return QK_OK;
+}
+
 int grow_table(qk_accum *a, uint64_t need, bool exact = false) {
   if (need <= a->table_len) return QK_OK;
   QK_HIP(hipDeviceSynchronize());
+  {   // the 32-bit side table goes into the old table first; the new one starts empty
+    int rc = fold_table32(a, a->stream);
+    if (rc) return rc;
+    QK_HIP(hipStreamSynchronize(a->stream));
+    if (a->d_table32) QK_HIP(hipFree(a->d_table32));
+    a->d_table32 = nullptr;
+  }
   // amortised doubling while reads arrive; `exact` when several accumulators
   // must agree on one geometry before their tables are summed
   uint64_t nl = exact ? need : std::max<uint64_t>(need, a->table_len * 2);
@@ -216,6 +235,8 @@ int grow_table(qk_accum *a, uint64_t need, bool exact = false) {
   }
   a->d_table = nt;
   a->table_len = nl;
+  QK_HIP(hipMalloc((void **)&a->d_table32, (size_t)QK_N_ROWS * nl * sizeof(uint32_t)));
+  QK_HIP(hipMemset(a->d_table32, 0, (size_t)QK_N_ROWS * nl * sizeof(uint32_t)));
   return QK_OK;
 }
 
@@ -629,6 +650,12 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.len_limit = strided ? max_len : 0u;
   if (hp.check_aligned || strided) a->status_armed = true;   // (strided: the length kernel vets lengths[])
   hp.table = a->d_table;
+  hp.table32 = getenv("QUACK_HIP_NO_TABLE32") ? nullptr : a->d_table32;
+  if (hp.table32) {
+    // a 32-bit counter takes at most one count per read and position: fold before 2^32 reads could have gone in
+    if (a->reads32 + n_reads > 0xFFFFFFFFull && (rc = fold_table32(a, st))) return rc;
+    a->reads32 += n_reads;
+  }
   hp.no_adapters = a->adapters ? 0 : 1;
   hp.first_hit = d_hit;
   hp.kmer_bits = a->d_kmer_bits;
@@ -1102,6 +1129,7 @@ void qk_accum_destroy(qk_accum *a) {
   if (a->d_kmer_filter) (void)hipFree(a->d_kmer_filter);
   if (a->d_kmer_buckets) (void)hipFree(a->d_kmer_buckets);
   if (a->d_table) (void)hipFree(a->d_table);
+  if (a->d_table32) (void)hipFree(a->d_table32);
   if (a->order_ev) (void)hipEventDestroy(a->order_ev);
   if (a->stream) (void)hipStreamDestroy(a->stream);
   delete a;
@@ -1488,6 +1516,17 @@ int qk_accum_stats(qk_accum *a, uint64_t *max_len, uint64_t *n_reads) {
   return QK_OK;
 }
 
+// everything submitted has run AND the 32-bit side table is part of d_table: what every reader of the table calls first
+static int settle(qk_accum *a) {
+  int rc = qk_accum_sync(a);
+  if (rc) return rc;
+  if (a->reads32) {
+    if ((rc = fold_table32(a, a->stream))) return rc;
+    QK_HIP(hipStreamSynchronize(a->stream));
+  }
+  return QK_OK;
+}
+
 int qk_accum_table_words(qk_accum *a, uint64_t *n_words) {
   if (!a || !n_words) return fail(QK_EINVAL, "NULL argument");
   *n_words = (uint64_t)QK_N_ROWS * a->table_len + 1;
@@ -1503,7 +1542,7 @@ int qk_accum_reserve(qk_accum *a, uint64_t max_len) {
 
 int qk_accum_export_table(qk_accum *a, void *d_dst, void *hip_stream) {
   if (!a || !d_dst) return fail(QK_EINVAL, "NULL argument");
-  int rc = qk_accum_sync(a);
+  int rc = settle(a);
   if (rc) return rc;
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : a->stream;
   const size_t words = (size_t)QK_N_ROWS * a->table_len;
@@ -1516,7 +1555,7 @@ int qk_accum_export_table(qk_accum *a, void *d_dst, void *hip_stream) {
 
 int qk_accum_import_table(qk_accum *a, const void *d_src, uint64_t max_len, void *hip_stream) {
   if (!a || !d_src) return fail(QK_EINVAL, "NULL argument");
-  int rc = qk_accum_sync(a);
+  int rc = settle(a);
   if (rc) return rc;
   if (max_len > a->table_len) return fail(QK_EINVAL, "max_len exceeds the table; call qk_accum_reserve first");
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : a->stream;
@@ -1538,7 +1577,7 @@ int qk_accum_allreduce(qk_accum **accs, int n) {
   // in a multi-process job; here the host already knows every shard)
   uint64_t max_len = 0, table_len = 0, total_reads = 0;
   for (int i = 0; i < n; ++i) {
-    int rc = qk_accum_sync(accs[i]);
+    int rc = settle(accs[i]);
     if (rc) return rc;
     max_len = std::max(max_len, accs[i]->max_len);
     table_len = std::max(table_len, accs[i]->table_len);
@@ -1604,7 +1643,7 @@ int qk_accum_allreduce(qk_accum **accs, int n) {
 int qk_accum_finish(qk_accum *a, qk_base_info *out, uint64_t cap_positions,
                     uint64_t *max_len, uint64_t *n_reads) {
   if (!a) return fail(QK_EINVAL, "acc is NULL");
-  int rc = qk_accum_sync(a);
+  int rc = settle(a);
   if (rc) return rc;
   if (max_len) *max_len = a->max_len;
   if (n_reads) *n_reads = a->n_reads;
