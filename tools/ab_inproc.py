@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--block", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--warm", type=int, default=80)
+    ap.add_argument("--shared", action="store_true", help="ONE accumulator for all settings (knobs read per submit only): "
+                    "where an accumulator's buffers land is worth up to 2 %% on some boxes")
     ap.add_argument("--dummy-streams", type=int, default=0, help="streams created (and kept) before the first accumulator")
     ap.add_argument("--dummy-mb", type=int, default=0, help="device memory allocated (and kept) before the first accumulator")
     ap.add_argument("settings", nargs="*")
@@ -59,6 +61,11 @@ def main():
     ballast = torch.empty(a.dummy_mb << 20, dtype=torch.uint8, device="cuda") if a.dummy_mb else None
     for s in settings:   # one accumulator per setting, created under it (some knobs are read at creation)
         lib = enter(s)
+        if a.shared and accs:
+            if lib is not None:
+                raise SystemExit("--shared cannot mix libraries")
+            accs[s] = accs[settings[0]]
+            continue
         accs[s] = quack_amd.Accumulator(0, ads_bits, max_len_hint=b["max_len"], _lib=lib)
     for s in settings:
         enter(s)
@@ -79,11 +86,17 @@ def main():
     tables = {}
     for s in settings:
         enter(s)
+        if a.shared and s != settings[0]:
+            continue
         sd = accs[s].finish()
         tables[s] = (sd.bases.copy(), sd.number_of_sequences)
         accs[s].close()
+    if a.shared:
+        settings_checked = settings[:1]
+    else:
+        settings_checked = settings
     first = tables[settings[0]]
-    for s in settings[1:]:   # every setting saw the same batches the same number of times
+    for s in settings_checked[1:]:   # every setting saw the same batches the same number of times
         same = tables[s][1] == first[1] and tables[s][0].shape == first[0].shape and bool((tables[s][0] == first[0]).all())
         if not same:
             print("!! the counters of %r differ from those of %r" % (s, settings[0]))
