@@ -616,6 +616,9 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    # (the host driver of this pool only supports dmabuf IPC; the boxes export this already — a launcher that
+    # scrubs the environment would otherwise end in `hipIpcGetMemHandle: invalid argument` inside RCCL)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
