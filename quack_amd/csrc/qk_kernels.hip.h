@@ -512,7 +512,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   // per quality row, lanes along positions (contiguous 512-B atomics).
   auto flush = [&](uint32_t tile) {
     const uint32_t P0 = tile * p.tile_pos;
-    if (!FIXED && tile == 0 && n_gt10) {
+    if (!FAST_FIXED && tile == 0 && n_gt10) {
       lds_add(lds_misc, 0, n_gt10);
       n_gt10 = 0;
     }
@@ -925,6 +925,17 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         if (SV) {   // nv[u] is the length of the read
           nl = (lane_on && nv[u] > cpos) ? nv[u] - cpos : 0u;
           nl = nl > 8u ? 8u : nl;
+          // length_count (quack.c:219) and the kmers==NULL count (quack.c:215) by the lane that owns the read's first
+          // chunk: the length is in its register anyway.  (Late round 3; round 2 counted behind the step loop, a pass
+          // of its own over lengths[], and gained nothing over the separate kernel: 24 us per 10M reads.)
+          if (!p.lengths_done && lane_on && chl == 0u && nv[u] != 0u) {
+            const uint32_t len = nv[u];
+            if (len > p.len_limit || len > TP) atomicOr(p.status, kStatusBadLength);   // (device-side lengths[] are only seen here)
+            else {
+              lds_add(lds_len, (len - 1u) * 4u, 1u);
+              n_gt10 += len > 10u ? 1u : 0u;
+            }
+          }
         }
         nU[u] = nl;
         liveU[u] = true;

@@ -632,7 +632,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     // (not a fused one-tile adapter batch: the histogram kernel is all of it, and two more events would add their own
     // ~10 us of stream time to what they measure)
     const bool one_kernel = pl.fused_adapters && pl.n_tiles == 1 && !getenv("QUACK_HIP_SEPARATE_COUNT");
-    if (pl.n_tiles > 1 || (a->adapters && !one_kernel) || strided) {
+    if (pl.n_tiles > 1 || (a->adapters && !one_kernel) || (strided && getenv("QUACK_HIP_LENGTH_KERNEL"))) {
       tl.b0 = get_event(a);
       tl.b1 = get_event(a);
       if (!tl.b0 || !tl.b1) return fail(QK_EHIP, "hipEventCreate failed");
@@ -695,7 +695,10 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   const bool aside = st == a->stream && a->side != nullptr && !getenv("QUACK_HIP_NO_SIDE");
   hipStream_t pre = aside ? a->side : st;
   int set = -1;
-  if (strided) {
+  // (one tile, the strided kernel variant itself: the lane that owns a read's first chunk counts its length inside the step
+  // loop — the separate pass over lengths[] was 24 us per 10M reads, 4.5 % of the batch)
+  const bool count_in_loop = strided && pl.n_tiles == 1 && !getenv("QUACK_HIP_LENGTH_KERNEL");
+  if (strided && !count_in_loop) {
     // strided batches have no staging pass that could count the lengths on the way
     // (ragged batches of several tiles: hist_kernel counts a read's length in the tile it ends in).
     // (on the side stream it would run BESIDE this batch's histogram kernel — nothing orders the two — and was measured:

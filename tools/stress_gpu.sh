@@ -9,7 +9,7 @@ K="not cli and not launch_configurations and not pipelined and not tuning_overri
 for e in "QUACK_HIP_TILE=64" "QUACK_HIP_THREADS=512" "QUACK_HIP_TILE=128 QUACK_HIP_THREADS=256 QUACK_HIP_UNROLL=2" \
          "QUACK_HIP_PIPE=2 QUACK_HIP_UNROLL=2" "QUACK_HIP_UNFUSED_ADAPTERS=1" "QUACK_HIP_REPLICAS=1" "QUACK_HIP_REPLICAS=2" \
          "QUACK_HIP_ADAPT_PD=3" "QUACK_HIP_ADAPT_PD=4 QUACK_HIP_ADAPT_U=1" "QUACK_HIP_SEPARATE_COUNT=1" \
-         "QUACK_HIP_NO_W16=1" "QUACK_HIP_NO_SIDE=1" "QUACK_HIP_NO_TABLE32=1" "QUACK_HIP_TILE_OVERHEAD=0"; do
+         "QUACK_HIP_NO_W16=1" "QUACK_HIP_NO_SIDE=1" "QUACK_HIP_NO_TABLE32=1" "QUACK_HIP_TILE_OVERHEAD=0" "QUACK_HIP_LENGTH_KERNEL=1"; do
   echo "== $e"
   env $e timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -rf -k "$K" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
 done
