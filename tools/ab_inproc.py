@@ -35,7 +35,7 @@ def main():
     ads_bits, ads = bench.synthetic_adapter_bits(np) if w["adapters"] else (None, None)
     b = bench.make_batch(torch, np, w, seed={"cfg3": 3, "cfg5": 6, "trimmed": 7}.get(a.workload, 2), device="cuda:0", quality="uniform", ads=ads)
     job = bench.Job.__new__(bench.Job)
-    keys = sorted({kv.split("=")[0] for s in settings for kv in s.split()} - {"LIB"})
+    keys = sorted({kv.split("=")[0] for s in settings for kv in s.split()} - {"LIB", "MODE"})
     libs = {}
 
     def enter(s):
@@ -44,15 +44,20 @@ def main():
         for k in keys:
             os.environ.pop(k, None)
         lib = None
+        mode = 0
         for kv in s.split():
             k, v = kv.split("=", 1)
-            if k == "LIB":
+            if k == "MODE":   # ablation builds (-DQK_ABLATION): 1 loads only, 2 quality only, 3 bases only
+                mode = int(v)
+            elif k == "LIB":
                 if v not in libs:
                     from quack_amd import _capi
                     libs[v] = _capi.bind_hip(ctypes.CDLL(os.path.abspath(v), mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND))
                 lib = libs[v]
             else:
                 os.environ[k] = v
+        if lib is not None and hasattr(lib, "qk_debug_set_mode"):
+            lib.qk_debug_set_mode(mode)
         return lib
 
     res = {s: ([], []) for s in settings}
