@@ -634,7 +634,9 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     const bool one_kernel = pl.fused_adapters && pl.n_tiles == 1 && !getenv("QUACK_HIP_SEPARATE_COUNT");
     if (pl.n_tiles > 1 || (a->adapters && !one_kernel) || (strided && getenv("QUACK_HIP_LENGTH_KERNEL"))) {
       tl.b0 = get_event(a);
-      tl.b1 = get_event(a);
+      // (nothing runs behind the histogram kernel unless the adapter hits are counted by kernels of their own: the batch
+      // then ends where the kernel does, one event for both)
+      if (a->adapters && !one_kernel) tl.b1 = get_event(a);
       if (!tl.b0 || !tl.b1) return fail(QK_EHIP, "hipEventCreate failed");
       QK_HIP(hipEventRecord(tl.b0, st));
     }
@@ -815,10 +817,8 @@ int drain_timing(qk_accum *a) {
     a->timing_launches += 1;
     a->event_pool.push_back(tl.t0);
     a->event_pool.push_back(tl.t1);
-    if (tl.b0 != tl.t0) {
-      a->event_pool.push_back(tl.b0);
-      a->event_pool.push_back(tl.b1);
-    }
+    if (tl.b0 != tl.t0) a->event_pool.push_back(tl.b0);
+    if (tl.b1 != tl.t1) a->event_pool.push_back(tl.b1);
   }
   a->timed.clear();
   return QK_OK;
@@ -1108,10 +1108,8 @@ void qk_accum_destroy(qk_accum *a) {
   for (auto &tl : a->timed) {
     (void)hipEventDestroy(tl.t0);
     (void)hipEventDestroy(tl.t1);
-    if (tl.b0 != tl.t0) {
-      (void)hipEventDestroy(tl.b0);
-      (void)hipEventDestroy(tl.b1);
-    }
+    if (tl.b0 != tl.t0) (void)hipEventDestroy(tl.b0);
+    if (tl.b1 != tl.t1) (void)hipEventDestroy(tl.b1);
   }
   for (auto e : a->event_pool) (void)hipEventDestroy(e);
   if (getenv("QUACK_HIP_DEBUG_ADDR"))   // (where this accumulator's buffers lay: tools/ab_inproc.py --addresses)
