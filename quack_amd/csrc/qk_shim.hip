@@ -779,7 +779,9 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
 
   // one tile: the histogram kernel resets first_hit[] and takes the kmer_count of its own reads
   hp.count_in_kernel = pl.fused_adapters && pl.n_tiles == 1 && !getenv("QUACK_HIP_SEPARATE_COUNT");
-  const bool ext_events = timed && !getenv("QUACK_HIP_MARKER_EVENTS");
+  // (opt-in: one full test run out of three stopped making progress the evening this went in — never reproduced, never
+  // traced to it either, so the markers stay the default)
+  const bool ext_events = timed && getenv("QUACK_HIP_EXT_EVENTS") != nullptr;
   if (timed && !ext_events) QK_HIP(hipEventRecord(tl.t0, st));
   if (pl.fused_adapters && !hp.count_in_kernel) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
   if (ext_events) t_ev0 = tl.t0, t_ev1 = tl.t1;
