@@ -60,6 +60,16 @@ WORKLOADS = {
                  label="10M-read synthetic 150 bp FASTQ, no adapters (BASELINE.json configs[1])"),
     "cfg3": dict(n=10_000_000, L=300, ragged=None, adapters=True, splice=0.25,
                  label="10M-read synthetic 300 bp FASTQ + adapter FASTA, 25% of reads with a spliced adapter (configs[2])"),
+    # the metric's own read length with the reference's flagship invocation (-a, /root/reference/images/makefile:8,14): 150 bp is
+    # not a multiple of 4, so the host feed lays such reads out at a stride of 152 (qk_accum_commit_padded) and the kernel
+    # takes 16 positions per lane (round 4); cfg3_150packed = the same reads 150 bytes apart (the 12-byte-window kernel)
+    "cfg3_150": dict(n=10_000_000, L=150, ragged=None, adapters=True, splice=0.25, pad=152,
+                     label="10M-read synthetic 150 bp FASTQ + adapter FASTA, 25% of reads with a spliced adapter, reads 152 bytes apart "
+                           "as the host feed lays them out (the metric's read length on configs[2]'s path)"),
+    "cfg3_150packed": dict(n=10_000_000, L=150, ragged=None, adapters=True, splice=0.25,
+                           label="10M-read synthetic 150 bp FASTQ + adapter FASTA, 25% of reads with a spliced adapter, packed"),
+    "cfg2pad": dict(n=10_000_000, L=150, ragged=None, adapters=False, pad=152,
+                    label="10M-read synthetic 150 bp FASTQ, no adapters, reads 152 bytes apart (experiment)"),
     # long reads live in HBM the way the host feed lays them out (pipeline.c): every read starts on a
     # 128-byte cache line (QK_BATCH_ALIGNED128); cfg5packed = the same reads without the padding
     "cfg5": dict(n=143_000, L=20000, ragged=(1000, 20000), adapters=False, aligned=True,
@@ -170,7 +180,7 @@ def make_batch(torch, np, w, seed, device, quality="uniform", q_hi_override=None
         q_lo, q_hi = (1, 60) if w["L"] > 1000 else (2, 41)
     else:
         total, max_len, d_off, d_len = w["n"] * w["L"], w["L"], None, None
-        extent = total
+        extent = w["n"] * w.get("pad", w["L"])   # (padded: the pad bytes hold letters and scores too, never counted)
         q_lo, q_hi = 2, (q_hi_override or 41)
     seq = torch.zeros(extent + 16, dtype=torch.uint8, device=device)
     qual = torch.zeros(extent + 16, dtype=torch.uint8, device=device)
@@ -189,7 +199,7 @@ def make_batch(torch, np, w, seed, device, quality="uniform", q_hi_override=None
     if ads is not None and w.get("splice") and d_off is None:
         # a quarter of the reads get one adapter at a uniform offset, truncated at the
         # read end — first-hit, hit-at-the-end and no-hit paths are all in the timed region
-        L, n = w["L"], w["n"]
+        L, n, S = w["L"], w["n"], w.get("pad", w["L"])
         pick = torch.nonzero(torch.rand(n, generator=g, device=device) < w["splice"]).flatten()
         which = torch.randint(0, len(ads), (len(pick),), generator=g, device=device)
         at = torch.randint(0, L, (len(pick),), generator=g, device=device)
@@ -200,10 +210,11 @@ def make_batch(torch, np, w, seed, device, quality="uniform", q_hi_override=None
             tab[i, :len(a)] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
         for j in range(width):
             ok = (at + j < L) & (j < alen[which])
-            seq[(pick * L + at + j)[ok]] = tab[which[ok], j]
+            seq[(pick * S + at + j)[ok]] = tab[which[ok], j]
         spliced = int(len(pick))
     return dict(seq=seq, qual=qual, d_off=d_off, d_len=d_len, total=total, max_len=max_len, extent=extent,
-                n=w["n"], spliced=spliced, stride=w.get("stride") if w["ragged"] else None)
+                n=w["n"], spliced=spliced, stride=w.get("stride") if w["ragged"] else None,
+                pad=w.get("pad") if not w["ragged"] else None)
 
 
 def synthetic_adapter_bits(np, seed=3):
@@ -238,6 +249,10 @@ def host_sample(np, b, w, budget_bases):
         gs, gq = b["seq"][:m * st].cpu().numpy().reshape(m, st), b["qual"][:m * st].cpu().numpy().reshape(m, st)
         keep = np.arange(st)[None, :] < lens[:m, None]
         return gs[keep], gq[keep], off[:m + 1], m, int(off[m])
+    if b.get("pad"):   # padded on the device: the oracle takes the same reads packed
+        m, L, st = min(n, max(1, budget_bases // w["L"])), w["L"], b["pad"]
+        gs, gq = b["seq"][:m * st].cpu().numpy().reshape(m, st), b["qual"][:m * st].cpu().numpy().reshape(m, st)
+        return np.ascontiguousarray(gs[:, :L]).reshape(-1), np.ascontiguousarray(gq[:, :L]).reshape(-1), None, m, m * L
     if b["d_off"] is None:
         m = min(n, max(1, budget_bases // w["L"]))
         return b["seq"][:m * w["L"]].cpu().numpy(), b["qual"][:m * w["L"]].cpu().numpy(), None, m, m * w["L"]
@@ -345,6 +360,8 @@ class Job:
     def submit(self, acc, b, stream):
         if b.get("stride"):
             acc.submit_device_strided(b["seq"], b["qual"], b["d_len"], b["n"], b["stride"], b["max_len"], stream=stream)
+        elif b.get("pad"):
+            acc.submit_device_padded(b["seq"], b["qual"], b["n"], b["max_len"], b["pad"], stream=stream)
         elif b["d_len"] is not None:
             acc.submit_device_gapped(b["seq"], b["qual"], b["d_off"], b["d_len"], b["n"], b["extent"], b["max_len"],
                                      aligned=True, stream=stream)
@@ -418,7 +435,7 @@ class Job:
         ranks = world if exchange else 1
         sd = acc.finish()
         got = int(sd.bases[:, 91:95].sum())
-        fixed = b["d_off"] is None and not b.get("stride")
+        fixed = b["d_off"] is None and not b.get("stride")   # (padded batches too: total counts the bases, not the pad bytes)
         if fixed or ranks == 1:
             if got != (warmup + steps) * b["total"] * ranks:
                 raise SystemExit("counter check failed (%s): content sum %d != %d" % (self.w["label"], got, (warmup + steps) * b["total"] * ranks))
@@ -646,6 +663,8 @@ def main():
         w["n"] = args.reads
     if args.read_len and not w["ragged"]:
         w["L"] = args.read_len
+        if w.get("pad"):
+            w["pad"] = (args.read_len + 3) & ~3
         w["label"] += " [read length overridden: %d]" % args.read_len
     job = Job(ctx, name, w, seed=2 + rank, seed_mate=1000 + rank)
 
@@ -738,10 +757,10 @@ def main():
     if rank == 0 and world == 1:
         if args.workload == "auto" and not args.no_also:
             also = {}
-            for nm in ("cfg3", "cfg5", "trimmed"):
-                j2 = Job(ctx, nm, dict(WORKLOADS[nm]), seed={"cfg3": 3, "cfg5": 6, "trimmed": 7}[nm], seed_mate=0)
+            for nm in ("cfg3", "cfg3_150", "cfg5", "trimmed"):
+                j2 = Job(ctx, nm, dict(WORKLOADS[nm]), seed={"cfg3": 3, "cfg3_150": 5, "cfg5": 6, "trimmed": 7}[nm], seed_mate=0)
                 entry = j2.line(j2.run(args.also_steps, args.also_warmup), 1, traffic_tab.get(nm))
-                if nm == "cfg3":
+                if nm.startswith("cfg3"):
                     entry["reads_with_spliced_adapter"] = j2.b["spliced"]
                 if not args.no_cpu_baseline:
                     entry["cpu_baseline"], _ = cpu_baselines(np, j2.b, j2.w, j2.ads, threads=False, budget=1_500_000_000)

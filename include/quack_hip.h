@@ -153,9 +153,22 @@ int qk_accum_commit_gapped(qk_accum *acc, uint64_t n_reads, uint64_t extent_byte
  * (quack_amd/host/pipeline.c).  Algorithmic traffic: 2 B/base + 4 B/read.
  * Pinned-slot form: lengths go into the array of qk_accum_slot_lengths. */
 int qk_accum_submit_device_strided(qk_accum *acc, const void *d_seq, const void *d_qual,
-                                   const void *d_lengths /* u32[n_reads] */, uint64_t n_reads,
+                                   const void *d_lengths /* u32[n_reads], or NULL: all max_len (padded fixed length) */, uint64_t n_reads,
                                    uint32_t stride, uint32_t max_len, void *hip_stream);
 int qk_accum_commit_strided(qk_accum *acc, uint64_t n_reads, uint32_t stride);
+/* Padded fixed-length batches (round 4): d_lengths == NULL above means "every read is max_len long" —
+ * a fixed-length batch whose reads lie `stride` (a multiple of 4, >= max_len) bytes apart.  Uniform reads
+ * whose length is not a multiple of 4 (150, 250, 125, 50 bp) start on odd byte phases when packed; padded,
+ * every 8-byte chunk starts on a dword and the batch runs the dword-aligned kernels (with the adapter scan:
+ * 16 positions per lane, one 16-byte load per lane and array).  The pad bytes are never counted.  Nothing in
+ * the reference corresponds (it holds one read at a time, quack.c:193); the counters are those of the packed
+ * batch.  Algorithmic traffic stays 2 B/base; the padding is 1.3 % more bytes at 150 bp.
+ *   qk_accum_padded_stride: the stride the library wants for uniform reads of read_len on this accumulator
+ *     (0: keep them packed — multiples of 4, no adapter scan, a tuning override).  The host feed asks it
+ *     (quack_amd/host/pipeline.c); qk_accum_submit_fixed pads by itself on the way into the pinned slot.
+ *   qk_accum_commit_padded: pinned-slot form; read r was written at r * stride of the acquired slot. */
+int qk_accum_padded_stride(qk_accum *acc, uint32_t read_len, uint32_t *stride);
+int qk_accum_commit_padded(qk_accum *acc, uint64_t n_reads, uint32_t read_len, uint32_t stride);
 /* copying feed from caller-owned host memory (any size; split internally) */
 int qk_accum_submit_strided(qk_accum *acc, const uint8_t *seq, const uint8_t *qual,
                             const uint32_t *lengths, uint32_t stride, uint64_t n_reads);

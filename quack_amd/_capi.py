@@ -74,6 +74,8 @@ def bind_hip(L):
     L.qk_accum_submit_device_strided.argtypes = [c_vp, c_vp, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint32,
                                                  ctypes.c_uint32, c_vp]
     L.qk_accum_commit_strided.argtypes = [c_vp, ctypes.c_uint64, ctypes.c_uint32]
+    L.qk_accum_padded_stride.argtypes = [c_vp, ctypes.c_uint32, c_u32p]
+    L.qk_accum_commit_padded.argtypes = [c_vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
     L.qk_accum_submit_strided.argtypes = [c_vp, c_vp, c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint64]
     L.qk_accum_slot_lengths.argtypes = [c_vp, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32))]
     L.qk_accum_commit_gapped.argtypes = [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]

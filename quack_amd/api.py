@@ -207,7 +207,23 @@ class Accumulator:
         """read r at [r*stride, r*stride + lengths[r]); lengths: int32/uint32[n] device tensor; stride % 4 == 0;
         see qk_accum_submit_device_strided"""
         _check(self._L.qk_accum_submit_device_strided(
-            self._h, d_seq.data_ptr(), d_qual.data_ptr(), d_lengths.data_ptr(), n_reads, stride, max_len, stream))
+            self._h, d_seq.data_ptr(), d_qual.data_ptr(), d_lengths.data_ptr() if d_lengths is not None else None,
+            n_reads, stride, max_len, stream))
+
+    def submit_device_padded(self, d_seq, d_qual, n_reads, read_len, stride, stream=None):
+        """fixed-length reads of read_len bases, read r at r*stride (stride % 4 == 0, >= read_len): the layout the host
+        feed gives uniform reads whose length is not a multiple of 4 (qk_accum_submit_device_strided, lengths NULL)"""
+        self.submit_device_strided(d_seq, d_qual, None, n_reads, stride, read_len, stream)
+
+    def padded_stride(self, read_len):
+        """the stride the library wants for uniform reads of read_len on this accumulator (0: packed)"""
+        s = ctypes.c_uint32()
+        _check(self._L.qk_accum_padded_stride(self._h, read_len, ctypes.byref(s)))
+        return s.value
+
+    def commit_padded(self, n_reads, read_len, stride):
+        """enqueue the acquired slot as a padded fixed-length batch (read r written at r*stride)"""
+        _check(self._L.qk_accum_commit_padded(self._h, n_reads, read_len, stride))
 
     def submit_device(self, d_seq, d_qual, d_offsets, n_reads, total_bytes, max_len, stream=None):
         """d_* expose data_ptr(); buffers need QK_TAIL_SLACK readable bytes

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kScanThreads) void adapter_scan_kernel(const HistPa
     uint64_t start;
     uint32_t len;
     if (FIXED) {
-      start = r * p.read_len;
+      start = r * (uint64_t)p.stride;
       len = p.lengths ? p.lengths[r] : p.read_len;   // (strided batch: fixed stride, own lengths)
     } else {
       start = p.offsets[r];

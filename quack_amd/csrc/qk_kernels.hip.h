@@ -92,6 +92,10 @@ struct HistParams {
   uint64_t total_bytes;         // offsets[n_reads]; loads are clamped to it
   uint64_t reads_per_slice;     // <= kMaxReadsPerSlice
   uint32_t read_len;            // fixed-length batches
+  uint32_t stride;              // fixed-length and strided batches: read r starts at r * stride.  == read_len for packed reads; a
+                                //   multiple of 4 just above it for PADDED ones (round 4: uniform reads whose length is not a
+                                //   multiple of 4 — 150, 250, 50 — laid out so that every chunk starts on a dword: the AL / W16
+                                //   kernels then run them; the pad bytes count into columns >= read_len, which are never flushed)
   uint32_t table_len;           // positions in `table`
   uint32_t n_tiles;             // position tiles
   uint32_t tile_pos;            // positions per tile (multiple of 8)
@@ -619,7 +623,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     // 32-bit byte offsets relative to a 4-byte-aligned, workgroup-uniform base
     uint64_t slice_base = 0;
     // (sorted: the slice's reads lie anywhere in the batch, which is < 4 GiB then: base 0)
-    if (slice_reads && !sorted) slice_base = FIXED ? r_begin * p.read_len : p.offsets[r_begin];
+    if (slice_reads && !sorted) slice_base = FIXED ? r_begin * p.stride : p.offsets[r_begin];
     if (!FIXED) {
       // offsets[] comes through a vector load: tell the compiler the value is the
       // same in every lane, or the two base pointers below live in VGPRs and
@@ -756,10 +760,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       // the only 32-bit integer multiply-add there is: quarter rate)
       uint32_t fixed_off0[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) fixed_off0[u] = FIXED ? ((uint32_t)u * RW + ri) * p.read_len + cposp : 0u;
+      for (int u = 0; u < U; ++u) fixed_off0[u] = FIXED ? ((uint32_t)u * RW + ri) * p.stride + cposp : 0u;
       auto issue = [&](uint32_t it, LoadT (&q)[U], LoadT (&s)[U], uint32_t (&nv)[U], uint32_t (&sk)[U],
                        uint32_t (&rl)[U]) __attribute__((always_inline)) {
-        const uint32_t it_bytes = FIXED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)it) * p.read_len : 0u;
+        const uint32_t it_bytes = FIXED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)it) * p.stride : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t rel = it + (uint32_t)u * RW + ri;   // index into the slice (FIXED) / the staged list

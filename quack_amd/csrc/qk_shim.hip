@@ -260,8 +260,11 @@ constexpr unsigned kQueueTiles = 1u << 17;  // counters per launch: reads of up 
 // Longer reads get tiles of <= 512 positions.  The grid is sized to residency:
 // workgroups per CU = what the LDS admits (at most 2 of 1024 threads).
 int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, bool gapped, bool aligned, Plan *pl,
-              bool base_aligned4 = true, bool strided = false) {
+              bool base_aligned4 = true, bool strided = false, uint32_t addr_stride = 0) {
   const uint32_t T = (uint32_t)a->threads;
+  // fixed-length reads: the distance between two reads — the read length, or (padded batches, round 4) the multiple of 4
+  // above it: what decides whether every chunk starts on a dword is the stride, not the length
+  const uint32_t fstride = addr_stride ? addr_stride : max_len;
   pl->fused_adapters = a->adapters && !getenv("QUACK_HIP_UNFUSED_ADAPTERS");
   // reads per lane and step / software pipeline depth.  Measured (10M x 150,
   // 5M x 300 + adapters, 1-20 kb ragged; kbench): fixed-length batches like
@@ -280,11 +283,11 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // fixed-length reads WITHOUT the adapter scan are memory-bound with 8 positions per lane at 70 VGPRs and lose 2-9 %
   // with 16 at 107 — 100 bp 0.341 -> 0.354 ms, 36 bp 0.140 -> 0.154 —, so they keep one chunk per lane)
   bool w16 = !tuned && !strided && !getenv("QUACK_HIP_NO_W16") &&
-             (ragged ? aligned : (pl->fused_adapters && (max_len & 3u) == 0 && base_aligned4 && !getenv("QUACK_HIP_NO_ALIGN4") &&
+             (ragged ? aligned : (pl->fused_adapters && (fstride & 3u) == 0 && base_aligned4 && !getenv("QUACK_HIP_NO_ALIGN4") &&
                                   // short reads whose last pair would be half empty lose more lanes than the pairs save
                                   // (36 bp: 48 columns for 36 positions, 0.236 -> 0.251 ms; 76 bp 0.417 -> 0.383, 100 bp 0.521 -> 0.497)
                                   (max_len >= 64 || round_up(max_len, 16) == round_up(max_len, 8))));
-  if (getenv("QUACK_HIP_W16_ALWAYS") && !tuned && !strided && !ragged && (max_len & 3u) == 0 && base_aligned4) w16 = true;   // (tests: the plain fixed-length variant)
+  if (getenv("QUACK_HIP_W16_ALWAYS") && !tuned && !strided && !ragged && (fstride & 3u) == 0 && base_aligned4) w16 = true;   // (tests: the plain fixed-length variant)
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
   uint32_t single_cap = 576u;
   while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, qk::hist_replicas(single_cap / 8), a->adapters, 0, ragged, qk::kStageReads, w16) > 160 * 1024)
@@ -323,7 +326,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   if (ragged && !pl->aligned) w16 = false;   // (a packed batch, or one tile: 12-byte windows)
   // fixed-length reads of a multiple of 4 bases: every chunk is dword aligned
   // (the batch base is: hipMalloc / pinned slots; submit_device checks it)
-  if (!ragged && (max_len & 3u) == 0 && base_aligned4 && T == 1024 && !a->unroll && !a->pipe &&
+  if (!ragged && (fstride & 3u) == 0 && base_aligned4 && T == 1024 && !a->unroll && !a->pipe &&
       !getenv("QUACK_HIP_NO_ALIGN4"))
     pl->aligned = true;
   if (pl->aligned && !ragged && pl->fused_adapters) pl->pipe = env_int("QUACK_HIP_ADAPT_PD", pl->pipe), pl->unroll = env_int("QUACK_HIP_ADAPT_U", pl->unroll);
@@ -400,7 +403,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // the kernel addresses a slice with 32-bit byte offsets
   // (a gapped batch is < 2 GiB as a whole, checked by the caller: any slice fits)
   if (!gapped) {
-    const uint64_t by_bytes = (0x7FFFFFFFull / std::max<uint32_t>(max_len, 1)) / step * step;
+    const uint64_t by_bytes = (0x7FFFFFFFull / std::max<uint32_t>(ragged ? max_len : fstride, 1)) / step * step;
     if (by_bytes < step) return fail(QK_EINVAL, "reads of %u bytes are too long for one slice", max_len);
     rcap = std::min(rcap, by_bytes);
   }
@@ -418,6 +421,20 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   if (pl->n_slices > 0xFFFFFF00ull) return fail(QK_EINVAL, "too many read slices");
   pl->n_blocks = pl->dynamic ? resident : pl->n_slices;   // persistent workgroups when dynamic
   return QK_OK;
+}
+
+// Padded fixed-length batches (round 4).  Uniform reads whose length is not a multiple of 4 — 150, 250, 125, 50 bp —
+// start on 2- or 1-byte phases when packed, so their chunks are fetched through 12-byte windows and re-aligned, and the
+// 16-positions-per-lane kernel (one dwordx4 per lane and array) cannot take them.  Laid out at a stride rounded up to 4 the
+// batch runs the dword-aligned kernels: with the adapter scan 150 bp went from 0.525 of the HBM peak to the 300-bp twin's
+// range (profiles/r04_lengths.log) for 1.3 % more bytes.  Returns the stride a feed should use for `read_len`, 0: packed.
+uint32_t padded_stride_for(const qk_accum *a, uint32_t read_len) {
+  if ((read_len & 3u) == 0 || getenv("QUACK_HIP_NO_PAD")) return 0;
+  if (a->unroll || a->pipe || a->threads != 1024 || getenv("QUACK_HIP_NO_ALIGN4")) return 0;   // (the aligned variants are the planner's own)
+  const bool always = getenv("QUACK_HIP_PAD_ALWAYS") != nullptr;
+  if (!a->adapters && !always) return 0;
+  if (read_len < 16u && !always) return 0;
+  return (read_len + 3u) & ~3u;
 }
 
 thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;   // set by the submit path for a timed launch, taken by launch_hist_tu
@@ -587,12 +604,15 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     return QK_OK;
   }
   Plan pl;
-  // three batch forms: packed (d_off, no d_len), gapped (d_off = starts, d_len), strided (no d_off, d_len, stride)
+  // batch forms: packed (d_off, no d_len), gapped (d_off = starts, d_len), strided (no d_off, d_len, stride), fixed length
+  // (none of them; stride == 0 or max_len: read r at r * max_len) and PADDED fixed length (stride > max_len, a multiple of 4)
   const bool strided = d_off == nullptr && d_len != nullptr;
+  const bool padded = d_off == nullptr && d_len == nullptr && stride > max_len;
+  if (padded && (stride & 3u)) return fail(QK_EINVAL, "a padded stride must be a multiple of 4");
   if (d_off && d_len && total_bytes > 0x7FFFFFF0ull) return fail(QK_EINVAL, "a gapped batch must stay below 2 GiB");
   rc = make_plan(a, n_reads, strided ? stride : max_len, d_off != nullptr, d_off && d_len,
                  d_off && d_len && (flags & QK_BATCH_ALIGNED128), &pl, (((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) == 0,
-                 strided);
+                 strided, padded ? stride : 0u);
   if (rc) return rc;
   if (strided) {
     // The strided kernel variant exists for the planner's own geometry only.  Under a tuning override
@@ -679,6 +699,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.total_bytes = total_bytes;
   hp.reads_per_slice = pl.reads_per_slice;
   hp.read_len = d_off ? 0 : (strided ? stride : max_len);
+  hp.stride = d_off ? 0 : ((strided || padded) ? stride : max_len);
   hp.table_len = (uint32_t)a->table_len;
   hp.n_tiles = pl.n_tiles;
   hp.tile_pos = pl.tile_pos;
@@ -1260,6 +1281,41 @@ int qk_accum_commit(qk_accum *a, uint64_t n_reads, uint64_t total, int offsets_u
   return QK_OK;
 }
 
+int qk_accum_padded_stride(qk_accum *a, uint32_t read_len, uint32_t *stride) {
+  if (!a || !stride) return fail(QK_EINVAL, "NULL argument");
+  *stride = padded_stride_for(a, read_len);
+  return QK_OK;
+}
+
+int qk_accum_commit_padded(qk_accum *a, uint64_t n_reads, uint32_t read_len, uint32_t stride) {
+  if (!a) return fail(QK_EINVAL, "acc is NULL");
+  if (a->held_slot < 0) return fail(QK_ESTATE, "no batch acquired");
+  if (stride == 0 || (stride & 3u) || read_len > stride) return fail(QK_EINVAL, "stride must be a multiple of 4 and >= read_len");
+  if (read_len == stride) return qk_accum_commit(a, n_reads, n_reads * (uint64_t)stride, 0, read_len);
+  Slot &s = a->slot[a->held_slot];
+  const uint64_t total = n_reads * (uint64_t)stride;
+  if (total > a->cap_bytes || n_reads > a->cap_reads) return fail(QK_EINVAL, "batch exceeds slot capacity");
+  int rc = set_device(a);
+  if (rc) return rc;
+  a->held_slot = -1;
+  a->next_slot ^= 1;
+  if (n_reads == 0) return QK_OK;
+  if (read_len == 0) {   // only empty reads: they count as sequences, nothing else
+    a->n_reads += n_reads;
+    return QK_OK;
+  }
+  if ((rc = grow_table(a, std::max<uint64_t>(read_len, 11)))) return rc;
+  memset(s.h_seq + total, 0, QK_TAIL_SLACK);
+  memset(s.h_qual + total, 0, QK_TAIL_SLACK);
+  QK_HIP(hipMemcpyAsync(s.d_seq, s.h_seq, total + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
+  QK_HIP(hipMemcpyAsync(s.d_qual, s.h_qual, total + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
+  rc = enqueue_batch(a, s.d_seq, s.d_qual, nullptr, s.d_hit, n_reads, total, read_len, s.stream, nullptr, 0, stride);
+  if (rc) return rc;
+  QK_HIP(hipEventRecord(s.done, s.stream));
+  s.busy = true;
+  return QK_OK;
+}
+
 int qk_accum_submit(qk_accum *a, const uint8_t *seq, const uint8_t *qual,
                     const uint64_t *offsets, uint64_t n_reads) {
   if (!a || !offsets || (n_reads && (!seq || !qual))) return fail(QK_EINVAL, "NULL argument");
@@ -1300,21 +1356,35 @@ int qk_accum_submit_fixed(qk_accum *a, const uint8_t *seq, const uint8_t *qual,
     a->n_reads += n_reads;
     return QK_OK;
   }
+  // the copy into the pinned slot re-lays the reads at a padded stride when that gives them the dword-aligned kernels
+  const uint32_t stride = padded_stride_for(a, read_len);
+  const uint32_t step = stride ? stride : read_len;
   uint64_t i = 0;
   while (i < n_reads) {
     uint8_t *hs, *hq;
     uint64_t *ho, capb, capr;
     int rc = qk_accum_acquire(a, &hs, &hq, &ho, &capb, &capr);
     if (rc) return rc;
-    uint64_t n = std::min<uint64_t>(n_reads - i, capb / read_len);
+    uint64_t n = std::min<uint64_t>(n_reads - i, capb / step);
     if (n == 0) {
       a->held_slot = -1;
-      if ((rc = qk_accum_resize_slots(a, read_len))) return rc;
+      if ((rc = qk_accum_resize_slots(a, step))) return rc;
       continue;
     }
-    memcpy(hs, seq + i * read_len, n * read_len);
-    memcpy(hq, qual + i * read_len, n * read_len);
-    if ((rc = qk_accum_commit(a, n, n * read_len, 0, read_len))) {
+    if (stride) {
+      for (uint64_t r = 0; r < n; ++r) {
+        memcpy(hs + r * stride, seq + (i + r) * read_len, read_len);
+        memcpy(hq + r * stride, qual + (i + r) * read_len, read_len);
+        memset(hs + r * stride + read_len, 0, stride - read_len);   // (never counted; kept defined)
+        memset(hq + r * stride + read_len, 0, stride - read_len);
+      }
+      rc = qk_accum_commit_padded(a, n, read_len, stride);
+    } else {
+      memcpy(hs, seq + i * read_len, n * read_len);
+      memcpy(hq, qual + i * read_len, n * read_len);
+      rc = qk_accum_commit(a, n, n * read_len, 0, read_len);
+    }
+    if (rc) {
       a->held_slot = -1;
       return rc;
     }
@@ -1375,8 +1445,9 @@ int qk_accum_submit_device_gapped(qk_accum *a, const void *d_seq, const void *d_
 
 int qk_accum_submit_device_strided(qk_accum *a, const void *d_seq, const void *d_qual, const void *d_lengths,
                                    uint64_t n_reads, uint32_t stride, uint32_t max_len, void *hip_stream) {
-  if (!a || (n_reads && (!d_lengths || (max_len && (!d_seq || !d_qual))))) return fail(QK_EINVAL, "NULL argument");
+  if (!a || (n_reads && max_len && (!d_seq || !d_qual))) return fail(QK_EINVAL, "NULL argument");
   if (stride == 0 || (stride & 3u) || max_len > stride) return fail(QK_EINVAL, "stride must be a multiple of 4 and >= max_len");
+  // d_lengths == NULL: every read is max_len long — a fixed-length batch at a padded stride
   if ((((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) != 0) return fail(QK_EINVAL, "strided batches must start on a 4-byte boundary");
   int rc = set_device(a);
   if (rc) return rc;

@@ -156,6 +156,39 @@ static void parallel_copy(copy_job *jobs, int n_jobs) {
   for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
 }
 
+/* an early batch of uniform reads into a pinned slot at a padded stride (qk_accum_commit_padded), on the same threads */
+typedef struct {
+  uint8_t *dst_seq, *dst_qual;
+  const uint8_t *src_seq, *src_qual;
+  uint64_t r0, r1;
+  uint32_t len, stride;
+} pad_job;
+static void *pad_main(void *p) {
+  const pad_job *j = p;
+  for (uint64_t r = j->r0; r < j->r1; r++) {
+    memcpy(j->dst_seq + r * j->stride, j->src_seq + r * j->len, j->len);
+    memcpy(j->dst_qual + r * j->stride, j->src_qual + r * j->len, j->len);
+    memset(j->dst_seq + r * j->stride + j->len, 0, j->stride - j->len);   /* (never counted; kept defined) */
+    memset(j->dst_qual + r * j->stride + j->len, 0, j->stride - j->len);
+  }
+  return NULL;
+}
+static void parallel_pad(uint8_t *dst_seq, uint8_t *dst_qual, const uint8_t *src_seq, const uint8_t *src_qual, uint64_t n,
+                         uint32_t len, uint32_t stride) {
+  pad_job job[COPY_THREADS];
+  pthread_t th[COPY_THREADS];
+  int started = 0;
+  for (int i = 0; i < COPY_THREADS; i++) {
+    job[i] = (pad_job){dst_seq, dst_qual, src_seq, src_qual, n * (uint64_t)i / COPY_THREADS, n * (uint64_t)(i + 1) / COPY_THREADS, len, stride};
+  }
+  for (int i = 0; i + 1 < COPY_THREADS; i++) {
+    if (pthread_create(&th[i], NULL, pad_main, &job[i])) break;
+    started++;
+  }
+  for (int i = started; i < COPY_THREADS; i++) pad_main(&job[i]);
+  for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+}
+
 /* heap for an early batch: 2 MiB aligned and marked for transparent huge pages where the kernel
  * offers them (first-touch faults and the later munmap are per page: 40 MB = 10,000 small ones) */
 static void *early_alloc(size_t n) {
@@ -260,6 +293,17 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       host_fail("%s", qk_last_error());
       goto out;
     }
+    uint32_t pad = 0;
+    if (e->uniform && !no_stride && (qk_accum_padded_stride(acc, e->uniform, &pad) || pad <= e->uniform)) pad = 0;
+    if (pad && (uint64_t)e->n * pad <= cap_bytes && (uint64_t)e->n <= cap_reads) {
+      /* uniform reads the library wants at a padded stride (see below): re-laid on the way into the slot */
+      parallel_pad(seq, qual, e->seq, e->qual, (uint64_t)e->n, e->uniform, pad);
+      if (qk_accum_commit_padded(acc, (uint64_t)e->n, e->uniform, pad)) {
+        host_fail("%s", qk_last_error());
+        goto out;
+      }
+      if (pad <= 512) stride = pad;   /* the batches behind the early ones are parsed into that layout directly */
+    } else
     if (e->total <= cap_bytes && (uint64_t)e->n <= cap_reads) {
       copy_job jobs[3] = {{seq, e->seq, e->total}, {qual, e->qual, e->total},
                           {offsets, e->off, e->uniform ? 0 : ((size_t)e->n + 1) * sizeof(uint64_t)}};
@@ -308,9 +352,10 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
         host_fail("%s: out of memory while parsing", path);
         goto out;
       }
-      /* all of one length after all, and the stride is that length: a plain fixed-length batch */
-      if (uniform == stride ? qk_accum_commit(acc, (uint64_t)n, (uint64_t)n * stride, 0, stride)
-                            : qk_accum_commit_strided(acc, (uint64_t)n, stride)) {
+      /* all of one length after all: a fixed-length batch — plain when the stride is that length, padded
+       * (qk_accum_commit_padded: uniform reads whose length is not a multiple of 4) when it is the next multiple of 4 */
+      if (uniform ? qk_accum_commit_padded(acc, (uint64_t)n, uniform, stride)
+                  : qk_accum_commit_strided(acc, (uint64_t)n, stride)) {
         host_fail("%s", qk_last_error());
         goto out;
       }
@@ -318,6 +363,12 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
        * packed batches */
       parked = qkh_reader_parked_len(rd);
       if (parked > stride) stride = parked <= 512 ? (uint32_t)((parked + 3) & ~3ull) : 0;
+      else if (n > 0 && !uniform) {
+        /* (no longer "nearly one length" — mean below 3/4 of the stride: the padding would be a third of the traffic) */
+        uint64_t sum = 0;
+        for (int64_t i = 0; i < n; i++) sum += lengths[i];
+        if (sum * 4 < (uint64_t)n * stride * 3) stride = 0;
+      }
       turn = (turn + 1) % n_devices;
       continue;
     }
@@ -356,6 +407,12 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       goto out;
     }
     if (n > 0) long_reads = total / (uint64_t)n >= 1024 && !getenv("QUACK_NO_ALIGN");
+    if (n > 0 && !long_reads && uniform && !no_stride) {
+      /* uniform reads: does the library want them at a padded stride (a length that is not a multiple of 4 with the
+       * adapter scan: dword-aligned chunks, 16 positions per lane)?  The following batches are then laid out that way. */
+      uint32_t want = 0;
+      if (qk_accum_padded_stride(acc, uniform, &want) == 0 && want > uniform && want <= 512) stride = want;
+    }
     if (n > 0 && !long_reads && !uniform && !no_stride) {
       /* a ragged batch of short reads: is it "one length, some of them trimmed"?  (longest read <= 512:
        * one position tile; mean >= 3/4 of it: the padding stays below a third of the traffic) */

@@ -38,7 +38,7 @@ struct qk_accum {
   uint32_t *len[2];
   int next, held;
   uint64_t cap_bytes, cap_reads;
-  unsigned long commits, gapped_commits, aligned_commits, strided_commits, copied_submits, resizes;
+  unsigned long commits, gapped_commits, aligned_commits, strided_commits, padded_commits, copied_submits, resizes;
 };
 
 int qk_accum_create(qk_accum **out, int device, const uint32_t *bits, uint64_t hint) {
@@ -68,8 +68,8 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *bits, uint64_t h
 void qk_accum_destroy(qk_accum *a) {
   if (!a) return;
   if (getenv("QK_DOUBLE_VERBOSE"))
-    fprintf(stderr, "[double] commits %lu gapped %lu aligned %lu strided %lu copied %lu resized %lu\n", a->commits, a->gapped_commits,
-            a->aligned_commits, a->strided_commits, a->copied_submits, a->resizes);
+    fprintf(stderr, "[double] commits %lu gapped %lu aligned %lu strided %lu copied %lu resized %lu padded %lu\n", a->commits, a->gapped_commits,
+            a->aligned_commits, a->strided_commits, a->copied_submits, a->resizes, a->padded_commits);
   for (int i = 0; i < 2; i++) {
     free(a->seq[i]);
     free(a->qual[i]);
@@ -183,6 +183,28 @@ int qk_accum_commit_strided(qk_accum *a, uint64_t n, uint32_t stride) {
   a->strided_commits++;
   for (uint64_t i = 0; i < n; i++)
     oracle_accumulate_read(&a->t, a->seq[s] + i * stride, a->qual[s] + i * stride, a->len[s][i], a->kmers);
+  return QK_OK;
+}
+
+/* padded fixed-length batches: the double wants them for uniform reads whose length is not a multiple of 4 when
+ * adapters are loaded (the product's rule), or for every such length with QK_DOUBLE_PAD_ALWAYS */
+int qk_accum_padded_stride(qk_accum *a, uint32_t read_len, uint32_t *stride) {
+  *stride = 0;
+  if ((read_len & 3u) && read_len >= 16 && (a->kmers || getenv("QK_DOUBLE_PAD_ALWAYS"))) *stride = (read_len + 3u) & ~3u;
+  return QK_OK;
+}
+
+int qk_accum_commit_padded(qk_accum *a, uint64_t n, uint32_t read_len, uint32_t stride) {
+  if (a->held < 0) return fail(QK_ESTATE, "no batch acquired");
+  const int s = a->held;
+  if (stride == 0 || (stride & 3u) || read_len > stride) return fail(QK_EINVAL, "stride must be a multiple of 4 and >= read_len");
+  if (n * (uint64_t)stride > a->cap_bytes || n > a->cap_reads) return fail(QK_EINVAL, "batch exceeds slot capacity");
+  release(a);
+  if (n == 0) return QK_OK;
+  a->commits++;
+  a->padded_commits++;
+  for (uint64_t i = 0; i < n; i++)
+    oracle_accumulate_read(&a->t, a->seq[s] + i * stride, a->qual[s] + i * stride, read_len, a->kmers);
   return QK_OK;
 }
 

@@ -99,6 +99,117 @@ def test_sixteen_positions_per_lane_every_shape(adapters, monkeypatch):
     assert not adapters or want[0][:, 96].sum() > 0
 
 
+def padded_layout(seq, qual, n, L, stride, seed=11):
+    """the reads of a packed fixed-length batch laid out `stride` bytes apart; the pad bytes are valid-looking letters
+    and scores that must never be counted"""
+    rng = np.random.default_rng(seed)
+    s2 = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (n, stride))].copy()
+    q2 = (33 + rng.integers(0, 60, (n, stride))).astype(np.uint8)
+    s2[:, :L] = seq.reshape(n, L)
+    q2[:, :L] = qual.reshape(n, L)
+    return s2.reshape(-1), q2.reshape(-1)
+
+
+@pytest.mark.parametrize("adapters", [False, True], ids=["plain", "adapters"])
+def test_padded_fixed_length_every_length(adapters, monkeypatch):
+    """round 4: uniform reads whose length is NOT a multiple of 4 (150, 250, 125, 50 bp) laid out at a stride rounded up
+    to 4 run the dword-aligned kernels — with the adapter scan the 16-positions-per-lane one.  Every read length 4..160
+    (and around the tile limits), adapters at every offset of a lane's 16 positions, through three routes into ONE
+    accumulator: the copying host feed (qk_accum_submit_fixed pads on the way into the pinned slot), the device API
+    with a padded layout (qk_accum_submit_device_strided, lengths NULL; garbage in the pad bytes), and the packed
+    device API (the 12-byte-window kernels): 3 x the oracle's table."""
+    import torch
+    if not adapters:
+        monkeypatch.setenv("QUACK_HIP_PAD_ALWAYS", "1")   # (the feeds pad by themselves only with the adapter scan)
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads) if adapters else None
+    bits = ob.kmers_to_bitset(k) if adapters else None
+    hits = 0
+    for L in list(range(4, 161)) + [249, 250, 251, 299, 301, 445, 446, 447, 449, 573, 575, 577, 601, 1001]:
+        n = 1200 if L <= 160 else 300
+        seq, qual = synth.fixed(n, L, seed=L, q_lo=0, q_hi=60)
+        seq = seq.copy().reshape(n, L)
+        if adapters and L >= 14:
+            for r in range(0, n, 3):
+                ad = np.frombuffer(ads[r % len(ads)], np.uint8)
+                at = (r // 3) % max(1, L - 10)
+                m = min(len(ad), L - at)
+                seq[r, at:at + m] = ad[:m]
+        seq = seq.reshape(-1)
+        want = ob.accumulate_batch(seq, qual, read_len=L, kmers=k)
+        hits += int(want[0][:, 96].sum())
+        stride = (L + 3) & ~3
+        s2, q2 = padded_layout(seq, qual, n, L, stride)
+        with quack_amd.Accumulator(0, bits) as acc:
+            assert acc.padded_stride(L) == (stride if L % 4 and L >= 16 or (L % 4 and not adapters) else 0)
+            acc.submit_fixed(seq, qual, L)
+            d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+            acc.submit_device_padded(d_s, d_q, n, L, stride)
+            p_s, p_q = torch.from_numpy(pad_for_device(seq)).cuda(), torch.from_numpy(pad_for_device(qual)).cuda()
+            acc.submit_device(p_s, p_q, None, n, n * L, L)
+            sd = acc.finish()
+        assert sd.number_of_sequences == 3 * want[1]
+        try:
+            assert_same((sd.bases, want[1]), (3 * want[0], want[1]))
+        except AssertionError as e:
+            raise AssertionError("read length %d: %s" % (L, e))
+    assert not adapters or hits > 1000
+
+
+def test_padded_batches_through_the_pinned_slots_and_under_overrides(monkeypatch):
+    """qk_accum_acquire / qk_accum_commit_padded (what the host feed drives), several batches with table growth in
+    between; and the padded form under tuning overrides, where the 12-byte-window kernels take the stride as it is"""
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    bits = ob.kmers_to_bitset(k)
+    total, n_all = None, 0
+    with quack_amd.Accumulator(0, bits) as acc:
+        for L in (50, 150, 151, 250):
+            n = 4000
+            seq, qual = synth.fixed(n, L, seed=L + 1)
+            seq = synth.splice_adapters(seq, L, ads, seed=L + 2, fraction=0.5)
+            want = ob.accumulate_batch(seq, qual, read_len=L, kmers=k)
+            stride = acc.padded_stride(L)
+            assert stride == (L + 3) & ~3
+            s2, q2 = padded_layout(seq, qual, n, L, stride)
+            hs, hq, _ = acc.acquire()
+            hs[:n * stride] = s2
+            hq[:n * stride] = q2
+            acc.commit_padded(n, L, stride)
+            grown = np.zeros((max(L, 0 if total is None else total.shape[0]), 97), np.uint64)
+            if total is not None:
+                grown[:total.shape[0]] += total
+            grown[:L] += want[0]
+            total, n_all = grown, n_all + n
+        sd = acc.finish()
+    assert_same((sd.bases, sd.number_of_sequences), (total, n_all))
+    seq, qual = synth.fixed(6000, 150, seed=9)
+    seq = synth.splice_adapters(seq, 150, ads, seed=10)
+    want = ob.accumulate_batch(seq, qual, read_len=150, kmers=k)
+    s2, q2 = padded_layout(seq, qual, 6000, 150, 152)
+    import torch
+    d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+    for cfg, env in ((dict(threads=512), {}), (dict(unroll=2), {}), ({}, {"QUACK_HIP_PIPE": "1"}), ({}, {"QUACK_HIP_NO_ALIGN4": "1"}),
+                     ({}, {"QUACK_HIP_NO_W16": "1"}), ({}, {"QUACK_HIP_UNFUSED_ADAPTERS": "1"}), ({}, {"QUACK_HIP_SEPARATE_COUNT": "1"}),
+                     ({}, {"QUACK_HIP_NO_PAD": "1"}), (dict(tile=64), {})):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        with quack_amd.Accumulator(0, bits) as acc:
+            if cfg:
+                acc.configure(**cfg)
+            acc.submit_device_padded(d_s, d_q, 6000, 150, 152)
+            acc.submit_fixed(seq, qual, 150)
+            sd = acc.finish()
+        assert_same((sd.bases, 6000), (2 * want[0], 6000))
+        for kk in env:
+            monkeypatch.delenv(kk)
+    with quack_amd.Accumulator(0) as acc:
+        with pytest.raises(quack_amd.HipUnavailable):
+            acc.submit_device_padded(d_s, d_q, 10, 150, 154)    # stride % 4
+        with pytest.raises(quack_amd.HipUnavailable):
+            acc.submit_device_padded(d_s, d_q, 10, 153, 152)    # read > stride
+
+
 def test_sixteen_positions_per_lane_on_and_off(monkeypatch):
     import torch
     ads = synth.synthetic_adapters()

@@ -130,6 +130,43 @@ def test_equal_length_reads_stay_fixed_length_batches(quack_double, tmp_path):
     assert [int(t) for t in a.stderr.decode().split("[double]")[1].split() if t.isdigit()][3] == 0
 
 
+def test_uniform_reads_of_an_odd_length_are_laid_out_at_a_padded_stride(quack_double, tmp_path):
+    """round 4: uniform reads whose length is not a multiple of 4 (150 bp) with the adapter scan: from the second batch on
+    (or from the first, for batches parsed while the accumulators start up) the pipeline writes them 152 bytes apart and
+    commits them with qk_accum_commit_padded; a batch that is not uniform goes on as a strided one, very ragged reads end
+    the mode; without adapters (the library does not ask for it) and with QUACK_NO_STRIDE nothing is padded; the SVG is
+    the packed pipeline's byte for byte"""
+    g = np.random.default_rng(21)
+    stats = lambda r: [int(t) for t in r.stderr.decode().split("[double]")[1].split() if t.isdigit()]
+    fq = tmp_path / "u150.fq"
+    write_fastq(fq, [150] * 4000, g)
+    for extra in ({}, {"QUACK_DEVICES": "0,1,2"}):
+        extra = dict(extra, QK_DOUBLE_SLOT_BYTES="20000", QK_DOUBLE_VERBOSE="1")
+        a = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], **extra)
+        b = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], QUACK_NO_STRIDE="1", **extra)
+        c = run(quack_double, ["-u", str(fq)], **extra)
+        d = run(quack_double, ["-u", str(fq)], QK_DOUBLE_PAD_ALWAYS="1", **extra)
+        e = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], early=True, QK_DOUBLE_CREATE_DELAY_MS="300",
+                **dict(extra, QK_DOUBLE_SLOT_BYTES="4000000"))   # (slots that hold an early batch: it is re-laid into one)
+        for r in (a, b, c, d, e):
+            assert r.returncode == 0, r.stderr[-2000:]
+        assert a.stdout == b.stdout == e.stdout and c.stdout == d.stdout and len(a.stdout) > 1000
+        n_acc = len(extra.get("QUACK_DEVICES", "0").split(","))
+        assert stats(a)[6] >= stats(a)[0] - n_acc and stats(a)[3] == 0, a.stderr        # all but the first batch (of every accumulator's turn)
+        assert stats(b)[6] == 0 and stats(c)[6] == 0 and stats(d)[6] > 5
+        assert sum(int(l.split()[-1]) for l in e.stderr.decode().splitlines() if l.startswith("[double]")) > 0, e.stderr   # (any accumulator)
+    # 150s, then a stretch trimmed to 120-149 (strided batches at the same stride), then reads of 20-150 (packed again)
+    lens = np.concatenate([[150] * 1500, np.where(g.random(1500) < 0.6, 150, g.integers(120, 150, 1500)), g.integers(20, 151, 1500),
+                           [150] * 1500])
+    fq2 = tmp_path / "mixed.fq"
+    write_fastq(fq2, lens, g)
+    a = run(quack_double, ["-u", str(fq2), "-a", "adapters.fa"], QK_DOUBLE_SLOT_BYTES="20000", QK_DOUBLE_VERBOSE="1")
+    b = run(quack_double, ["-u", str(fq2), "-a", "adapters.fa"], QK_DOUBLE_SLOT_BYTES="20000", QK_DOUBLE_VERBOSE="1", QUACK_NO_STRIDE="1")
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 1000
+    commits, gapped, aligned, strided, copied, resized, padded = stats(a)[:7]
+    assert padded > 15 and strided > 5 and commits - padded - strided > 5, a.stderr
+
+
 def test_reads_parsed_while_the_accumulators_start_up(quack_double, tmp_path):
     """a slow HIP start-up (here: the double sleeps in qk_accum_create): the tokenizer fills heap batches
     meanwhile and hands them to the copying feed; same SVG, also when the process exits without teardown

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 4: the padded layout against the packed one, same box (tests first)
+set -o pipefail
+mkdir -p gpurun_out
+( time python -c "import torch; print(torch.__version__)" ) > gpurun_out/r4_quick_import.log 2>&1   # (a fresh box pages the image in: minutes, once)
+B="--steps 50 --warmup 100 --no-also --no-cpu-baseline --no-tiers --no-traffic --no-steady"
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -v -x -k "padded or sixteen or adapters_fixed or chunk_count or strided" > gpurun_out/r4_quick_tests.log 2>&1 || { tail -30 gpurun_out/r4_quick_tests.log; exit 1; }
+tail -3 gpurun_out/r4_quick_tests.log
+for w in cfg3_150 cfg3_150packed cfg3_150 cfg3_150packed cfg2 cfg2pad cfg2 cfg2pad cfg3; do
+  echo "== $w" >> gpurun_out/r4_quick_bench.log
+  timeout -k 10 300 python bench.py --workload $w $B >> gpurun_out/r4_quick_bench.log 2>gpurun_out/r4_quick_err.log || { tail -20 gpurun_out/r4_quick_err.log; exit 1; }
+done
+python - <<'PY'
+import json
+for l in open("gpurun_out/r4_quick_bench.log"):
+    if l.startswith("=="): name=l.strip(); continue
+    d=json.loads(l); r=d["roofline"]
+    print(name, "ms/step %.4f kernel %.4f frac %.4f" % (d["ms_per_step"], r["kernel_ms"], r["frac"]))
+PY
