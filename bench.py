@@ -114,6 +114,8 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=None, help="override reads per GPU (rehearsals)")
     ap.add_argument("--read-len", type=int, default=None,
                     help="override the read length of a fixed-length workload (kernel exploration; the line says so)")
+    ap.add_argument("--splice", type=float, default=None,
+                    help="override the share of reads that carry a spliced adapter (kernel exploration; the line says so)")
     ap.add_argument("--quality", default="uniform", choices=["uniform", "novaseq4"],
                     help="novaseq4: Q in {2,12,23,37} with 3/5/12/80 %% (stress for same-bin LDS atomics)")
     return ap.parse_args()
@@ -666,6 +668,9 @@ def main():
         if w.get("pad"):
             w["pad"] = (args.read_len + 3) & ~3
         w["label"] += " [read length overridden: %d]" % args.read_len
+    if args.splice is not None and w.get("splice") is not None:
+        w["splice"] = args.splice
+        w["label"] += " [spliced share overridden: %g]" % args.splice
     job = Job(ctx, name, w, seed=2 + rank, seed_mate=1000 + rank)
 
     # N > 1: the SAME per-GPU workload on rank 0 alone, before the group forms (the other ranks are waiting in the

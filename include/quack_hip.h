@@ -224,6 +224,10 @@ int qk_accum_configure(qk_accum *acc, int threads_per_wg, int unroll,
 int qk_debug_plan(uint64_t n_reads, uint32_t max_len, int ragged, int adapters,
                   uint32_t bucket_log2, int gapped, int aligned, int n_cu,
                   uint64_t *out);
+/* How a fixed-length batch with the adapter scan is cut into rows of several reads (16-position lanes filled better:
+ * 150 bp at stride 152 -> two reads per row); out[8]: group, row positions, tile_pos, rows/iter, unroll, w16,
+ * bucket_log2, LDS bytes. */
+int qk_debug_group(uint64_t n_reads, uint32_t read_len, uint32_t stride, uint32_t bucket_log2, uint64_t *out);
 /* Ablation builds of the histogram kernel (-DQK_ABLATION, tools/kbench only);
  * the product library only has mode 0 and rejects any other at launch. */
 int qk_debug_set_mode(int mode);

@@ -96,6 +96,15 @@ struct HistParams {
                                 //   multiple of 4 just above it for PADDED ones (round 4: uniform reads whose length is not a
                                 //   multiple of 4 — 150, 250, 50 — laid out so that every chunk starts on a dword: the AL / W16
                                 //   kernels then run them; the pad bytes count into columns >= read_len, which are never flushed)
+  // Grouped rows (round 4; fixed-length reads with the fused adapter scan, 16 positions per lane, one tile): a ROW of the
+  // batch is `group` consecutive reads, `gstride` bytes apart, and the kernel treats it as one long read of
+  // (group - 1) * gstride + read_len positions — `stride` is then the distance between rows, n_reads counts rows.  A read of
+  // 150 bases takes 10 lanes of 16 positions (6 % of them idle), two reads 152 bytes apart take 19; 100 bp: 7 lanes for
+  // one read, 19 for three; 36 bp: 3 for one, 9 for four.  Only the rare paths know about it: the flush folds the column
+  // groups onto positions, the spill and the candidate check ask which read a column belongs to.
+  uint32_t fh_words;            // words of the first-hit ring in LDS (a power of two >= kFhRing; fused adapters, fixed length)
+  uint32_t group;               // reads per row (>= 1)
+  uint32_t gstride;             // bytes between the reads of a row (group > 1)
   uint32_t table_len;           // positions in `table`
   uint32_t n_tiles;             // position tiles
   uint32_t tile_pos;            // positions per tile (multiple of 8)
@@ -217,7 +226,11 @@ constexpr uint32_t kStageReadsMax = 8192;
 // against the exact table when the queue holds a wave's worth of entries.
 constexpr uint32_t kCandCap = 96;                       // entries per wave: drained above 32, a step adds <= 64
 constexpr uint32_t kCandWords = 16u * kCandCap * 2u;    // 16 waves x 96 entries x 8 bytes = 12 KiB
-constexpr uint32_t kCandWords16 = 16u * kCandCap * 4u;  // W16 builds: one 16-byte entry per LANE (16 positions): 24 KiB
+// W16 builds: one 16-byte entry per LANE (16 positions).  Round 4: 64 entries per wave, checked when a step's entries would
+// not fit any more — nearly a full wave's worth per check (the rule above ran the checks of 25 % spliced 150 bp reads with 33-45 of
+// their 64 lanes) — and 16 KiB instead of 24: the 8 KiB go to the first-hit ring (HistParams::fh_words)
+constexpr uint32_t kCandCap16 = 64;
+constexpr uint32_t kCandWords16 = 16u * kCandCap16 * 4u;
 // First hits of a fixed-length one-tile batch stay in the LDS (round 3): all lanes of a read sit in one workgroup in
 // one step, so min(first hit) needs no global memory — a ring of kFhRing words indexed by the read's place in the
 // slice, folded into the kmer_count row and cleared every G <= kFhRing / 2 reads behind a workgroup barrier (every
@@ -225,12 +238,14 @@ constexpr uint32_t kCandWords16 = 16u * kCandCap * 4u;  // W16 builds: one 16-by
 // per 10M x 300, each a random 128-byte line of a 40 MB array through the L2 and, gfx9 having ONE counter for loads
 // and atomics, inside the wait for the next step's loads — 7-10 % of the kernel, measured by leaving the atomic out;
 // plus the reset of that array before and its read-back after the loop.
-constexpr uint32_t kFhRing = 2048;
+constexpr uint32_t kFhRing = 2048;      // the smallest ring (what fits beside a 304-position histogram); HistParams::fh_words is the launch's
+constexpr uint32_t kFhRingMax = 16384;  // (round 4: the planner takes the largest power of two the LDS has room for — a fold every
+                                        //  fh_words / 2 reads costs every wave a drain of its queue, however empty, and a barrier)
 inline size_t hist_lds_bytes(uint32_t ch, uint32_t replicas, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false,
-                             uint32_t stage_reads = kStageReads, bool w16 = false) {
+                             uint32_t stage_reads = kStageReads, bool w16 = false, uint32_t fh_words = kFhRing) {
   return ((size_t)kQRows * hist_row_dwords(ch, replicas) + (adapt ? 6u : 5u) * 8u * ch + 4u + (adapt ? kFusedFilterWords + (w16 ? kCandWords16 : kCandWords) : 0u)) * sizeof(uint32_t) +
          (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)stage_reads * (adapt ? 12 : 8) : 0) +
-         (adapt && !ragged ? (size_t)kFhRing * 4 : 0);   // fixed-length batches: the first-hit ring (where a ragged batch stages its reads)
+         (adapt && !ragged ? (size_t)fh_words * 4 : 0);   // fixed-length batches: the first-hit ring (where a ragged batch stages its reads)
 }
 
 // The fused path works on COMPLEMENTED 2-bit codes (3 - code: the "not T / not C /
@@ -397,6 +412,22 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   uint32_t *lds_fh = reinterpret_cast<uint32_t *>(lds_list);          // ADAPT, FIXED: the first-hit ring (kFhRing words)
 
   const uint64_t TL = p.table_len;
+  // grouped rows (HistParams::group): built into the one variant the planner uses them with
+  constexpr bool GROUPS = W16 && ADAPT && FIXED && !SV;
+  const uint32_t GRP = GROUPS ? p.group : 1u;
+  const uint32_t GS = GROUPS ? p.gstride : 0u;
+  const uint32_t row_len = FIXED ? (GRP - 1u) * GS + p.read_len : 0u;   // positions of a row that hold reads (SV: the stride)
+  // column c of a row -> the read of the row it belongs to and the position in that read
+  auto col_split = [&](uint32_t c, uint32_t &g, uint32_t &pos) {
+    g = 0u;
+    pos = c;
+    if constexpr (GROUPS) {
+      if (GRP > 1u) {
+        g = c / GS;
+        pos = c - g * GS;
+      }
+    }
+  };
 
   if (ADAPT) {
     for (uint32_t i = tid; i < kFusedFilterWords; i += T) lds_filter[i] = p.kmer_filter[kFusedFilterWords + i];
@@ -428,9 +459,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   const bool lane_on = lane_id >= feeders && !is_halo && ri < RW;
   // one tile, fixed length: first hits are kept in lds_fh, see kFhRing (wave-uniform, the same for the whole launch;
   // a step of more reads than half the ring — reads of a chunk or two — keeps the global words)
-  const bool fh_ring = ADAPT && FIXED && p.count_in_kernel != 0 && RW * (uint32_t)U <= kFhRing / 2u;
-  // reads between two folds of the ring: whole steps, at most half the ring
-  const uint32_t fh_group = fh_ring ? (kFhRing / 2u) / (RW * (uint32_t)U) * (RW * (uint32_t)U) : 0u;
+  const uint32_t FHW = (ADAPT && FIXED) ? p.fh_words : kFhRing, FHM = FHW - 1u;
+  const bool fh_ring = ADAPT && FIXED && p.count_in_kernel != 0 && RW * (uint32_t)U * GRP <= FHW / 2u;
+  // rows between two folds of the ring: whole steps, their reads at most half the ring
+  const uint32_t fh_group = fh_ring ? (FHW / 2u / GRP) / (RW * (uint32_t)U) * (RW * (uint32_t)U) : 0u;
   constexpr bool kScalarLoop = W16 && ADAPT && FIXED;   // see the step loop
   uint32_t fh_folded = 0, fh_next = 0xFFFFFFFFu;   // reads of the slice whose ring entries have been folded; the next fold point (wave-uniform)
   // the lane's K chunks of the tile and their LDS columns.  W16: chunks 2*chl and 2*chl + 1; the even chunks of a
@@ -458,7 +490,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
 
   // ADAPT: this wave's candidate queue (see kCandCap) and its fill (wave-uniform)
   uint2 *cand_q = reinterpret_cast<uint2 *>(lds_raw + kFusedFilterWords) + (tid >> 6) * kCandCap;
-  uint4 *cand_q16 = reinterpret_cast<uint4 *>(lds_raw + kFusedFilterWords) + (tid >> 6) * kCandCap;   // W16: 16-byte entries
+  uint4 *cand_q16 = reinterpret_cast<uint4 *>(lds_raw + kFusedFilterWords) + (tid >> 6) * kCandCap16;   // W16: 16-byte entries
   uint32_t cand_n = 0;
   uint32_t n_gt10 = 0;        // reads longer than 10 (kmers==NULL path, quack.c:215)
   uint32_t fixed_reads = 0;   // FIXED, tile 0: reads seen since the last flush
@@ -471,12 +503,12 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   // the spill takes events - count.  Masked bytes are "not equal" in every
   // event, so they come out as zero.  `events` = accumulated steps since the
   // last spill (wave-uniform).  Fixed-length batches without the adapter scan
-  // go one step further: the tail is a per-lane constant (fixed_nc), lanes past
+  // go one step further: the tail is a per-lane constant (fixed_mask), lanes past
   // the end of the slice sit out under the exec mask and count their own
   // events (steps_v), and no per-event valid counter is needed at all.
   constexpr bool FAST_FIXED = FIXED && !SV;
   uint32_t events = 0, steps_v = 0;
-  uint32_t fixed_nc = 0;   // FIXED: how many of the lane's 8K positions lie inside the read (the same for every read)
+  uint32_t fixed_mask = 0;   // FIXED: which of the lane's 8K positions are bases of a read (the same for every row): bit i = position cpos + i
 
   auto spill = [&]() {
 #pragma unroll
@@ -485,7 +517,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       for (int b = 0; b < 4; ++b) {
         const uint32_t off = (8u * chk[d >> 1] + 4u * (d & 1) + b) * 4u;
         uint32_t v = events - ((acc_v[d] >> (8 * b)) & 0xFFu);   // acc_v counts the events in which the byte was masked
-        if (FAST_FIXED) v = (uint32_t)(4 * d + b) < fixed_nc ? steps_v : 0u;
+        if (FAST_FIXED) v = ((fixed_mask >> (4 * d + b)) & 1u) ? steps_v : 0u;
         if (v == 0) continue;  // nothing valid => no T/C/G either
         lds_add(lds_base, off, v);
         uint32_t t = (acc_t[d] >> (8 * b)) & 0xFFu;
@@ -524,13 +556,18 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     // fixed-length batches count unmasked: columns at and behind read_len hold the next read's bytes
     const uint32_t pos_limit = (FIXED && p.read_len < p.table_len) ? p.read_len : p.table_len;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
+    // grouped rows: position pp of the reads lives in the columns pp, pp + gstride, ... (one per read of a row); summed here
+    const uint32_t span = (GROUPS && GRP > 1u) ? p.read_len : TP;
     for (uint32_t row = 33u + wave; row <= 123u; row += T / 64) {  // quack.c:203: bin = byte - 33
-      for (uint32_t pp = lane; pp < TP; pp += 64u) {
-        const uint32_t c8 = pp >> 3, j = pp & 7u;
+      for (uint32_t pp = lane; pp < span; pp += 64u) {
         uint32_t c = 0;
-        for (uint32_t rep = 0; rep < R; ++rep) {
-          const uint32_t w = lds[qhist_index(row, (rep * 4u + (j & 3u)) * CH + lds_col(c8))];
-          c += (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
+        for (uint32_t gi = 0; gi < GRP; ++gi) {
+          const uint32_t col = pp + gi * GS;
+          const uint32_t c8 = col >> 3, j = col & 7u;
+          for (uint32_t rep = 0; rep < R; ++rep) {
+            const uint32_t w = lds[qhist_index(row, (rep * 4u + (j & 3u)) * CH + lds_col(c8))];
+            c += (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
+          }
         }
         const uint32_t pos = P0 + pp;
         if (c != 0 && pos < pos_limit) {
@@ -539,11 +576,17 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         }
       }
     }
-    for (uint32_t pp = tid; pp < TP; pp += T) {
-      const uint32_t v = lds_base[pp];
+    for (uint32_t pp = tid; pp < span; pp += T) {
+      uint32_t v = 0, t = 0, c = 0, g = 0;
+      for (uint32_t gi = 0; gi < GRP; ++gi) {
+        const uint32_t col = pp + gi * GS;
+        v += lds_base[col];
+        t += lds_base[TP + col];
+        c += lds_base[2u * TP + col];
+        g += lds_base[3u * TP + col];
+      }
       const uint32_t pos = P0 + pp;
       if (v == 0 || pos >= pos_limit) continue;
-      const uint32_t t = lds_base[TP + pp], c = lds_base[2u * TP + pp], g = lds_base[3u * TP + pp];
       const uint32_t a = v - t - c - g;                     // content[] order: A,T,C,G (quack.c:150)
       if (p.table32) {
         uint32_t *row0 = &p.table32[(uint64_t)kRowContent * TL + pos];
@@ -577,7 +620,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     if (tile == 0) {
       if (FAST_FIXED) {
         if (tid == 0 && fixed_reads != 0) {
-          const unsigned long long n = fixed_reads;
+          const unsigned long long n = (unsigned long long)fixed_reads * GRP;   // (fixed_reads counts rows)
           if (p.read_len != 0)
             atomicAdd(&p.table[(uint64_t)kRowLength * TL + p.read_len - 1u], n);   // quack.c:219
           if (p.no_adapters && p.read_len > 10u)
@@ -609,7 +652,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     // 45 us of a 1.5 ms step on 10M x 300.  Reset here, count below, both with device-coherent
     // accesses: the atomicMin of the drain happens at the memory side.
     if (fh_ring) {
-      for (uint32_t i = tid; i < kFhRing; i += T) lds_fh[i] = kNoHit;
+      for (uint32_t i = tid; i < FHW; i += T) lds_fh[i] = kNoHit;
       fh_folded = 0;
       fh_next = fh_group;
       __syncthreads();
@@ -641,7 +684,19 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     const uint32_t off_limit = room < 0xFFFFFFF0ull ? (uint32_t)room : 0xFFFFFFF0u;
     const uint32_t cposp = cpos + (uint32_t)(slice_base & 3ull);
     // the lane's chunks cover the same bytes of every read of a fixed-length batch
-    if (FIXED) fixed_nc = (lane_on && p.read_len > cpos) ? (p.read_len - cpos > 8u * K ? 8u * K : p.read_len - cpos) : 0u;
+    if (FIXED) {
+      fixed_mask = 0u;
+      uint32_t g, pos;
+      col_split(cpos, g, pos);
+      for (uint32_t i = 0; i < 8u * K; ++i) {
+        if (lane_on && cpos + i < row_len && g < GRP && pos < p.read_len) fixed_mask |= 1u << i;
+        ++pos;
+        if (GROUPS && GRP > 1u && pos == GS) {
+          pos = 0u;
+          ++g;
+        }
+      }
+    }
 
     // Fixed-length batches: one pass over the slice, read r at r*L.  Ragged
     // batches: passes of stage_reads reads; each pass first stages, in LDS, the
@@ -664,12 +719,13 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     // drained: the callers drain and meet at a barrier first).  quack.c:211-217: i ends one past the first window
     // found; counted iff i < l.
     auto fold_first_hits = [&](uint32_t upto) {
-      for (uint32_t rel = fh_folded + tid; rel < upto; rel += T) {
-        const uint32_t v = lds_fh[rel & (kFhRing - 1u)];
+      // (grouped rows: the ring holds one word per READ, row * group + the read's place in the row)
+      for (uint32_t rel = fh_folded * GRP + tid; rel < upto * GRP; rel += T) {
+        const uint32_t v = lds_fh[rel & FHM];
         if (v == kNoHit) continue;
         const uint32_t len = SV ? p.lengths[(size_t)r_begin + rel] : p.read_len;
         if (v + 1u < len && v + 1u < TP) lds_add(lds_kmer, 4u * (v + 1u), 1u);
-        lds_fh[rel & (kFhRing - 1u)] = kNoHit;
+        lds_fh[rel & FHM] = kNoHit;
       }
       fh_folded = upto;
     };
@@ -772,7 +828,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           uint32_t off, len;
           if (FIXED) {
             off = it_bytes + fixed_off0[u];
-            len = p.read_len;
+            len = row_len;
           } else {
             const uint2 e = PD > 1 ? lds_list[in_list ? rel : 0u] : de[u];
             off = e.x + cpos;
@@ -826,7 +882,6 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       // those), probe bits << 24 | lane << 16, rel} — one entry per LANE, 16 windows.
       auto drain_candidates = [&]() {
         constexpr uint32_t NW = 8u * K;                 // windows per entry
-        constexpr uint32_t kAll = (1u << NW) - 1u;
         for (uint32_t i = lane_id; i < ((cand_n + 63u) & ~63u); i += 64u) {   // whole waves: bpermute below
           uint32_t src, rel, hits, s_lo, s_hi;
           if constexpr (W16) {
@@ -859,22 +914,41 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             rd = lds_ridx[rel];
           }
           hits = i < cand_n ? hits : 0u;
-          // only windows that end inside the read, at e >= 9 (quack.c:206-213)
-          const uint32_t n = len - cp;   // > 0: the lane counted something
-          hits &= n >= NW ? kAll : (1u << n) - 1u;
-          hits &= cp >= 9u ? kAll : (kAll & ~((1u << (9u - cp)) - 1u));
+          // only windows that end inside the read, at e >= 9 (quack.c:206-213): those of the lane's windows j whose
+          // position base + j lies in [9, ln)
+          auto window_mask = [&](int32_t base, uint32_t ln) -> uint32_t {
+            int32_t lo = 9 - base, hi = (int32_t)ln - base;
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > (int32_t)NW ? (int32_t)NW : hi;
+            return hi > lo ? (((1u << (uint32_t)(hi - lo)) - 1u) << (uint32_t)lo) : 0u;
+          };
           const uint64_t stream = ((uint64_t)s_hi << 32) | s_lo;
-          uint32_t found = kNoHit;
-          while (hits) {
-            const uint32_t j = (uint32_t)__builtin_ctz(hits);
-            hits &= hits - 1u;
-            // the window ending at owned position j = bits [2*(NW-1-j), 2*(NW-1-j)+20) of the (complemented) code stream
-            const uint32_t km = ((uint32_t)(stream >> (2u * (NW - 1u - j))) & kKmerMask) ^ kKmerMask;
-            const bool in_table = p.bucket_log2 ? bucket_has(lds_buckets, km, p.bucket_mul, p.bucket_log2)
-                                                : ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) != 0;
-            if (in_table) {
-              found = cp + j;
-              break;   // later windows of this chunk are later positions
+          // the first window of `h` whose 10-mer is in the table (later windows are later positions), or NW
+          auto first_in_table = [&](uint32_t h) -> uint32_t {
+            while (h) {
+              const uint32_t j = (uint32_t)__builtin_ctz(h);
+              h &= h - 1u;
+              // the window ending at owned position j = bits [2*(NW-1-j), 2*(NW-1-j)+20) of the (complemented) code stream
+              const uint32_t km = ((uint32_t)(stream >> (2u * (NW - 1u - j))) & kKmerMask) ^ kKmerMask;
+              const bool in_table = p.bucket_log2 ? bucket_has(lds_buckets, km, p.bucket_mul, p.bucket_log2)
+                                                  : ((p.kmer_bits[km >> 5] >> (km & 31u)) & 1u) != 0;
+              if (in_table) return j;
+            }
+            return NW;
+          };
+          // grouped rows: the lane's positions belong to read g0 of its row from position pos0 on and, past that read's
+          // stride, to read g0 + 1 from its position 0 on (a stride is at least 16 positions: two reads at most)
+          uint32_t g0, pos0;
+          col_split(cp, g0, pos0);
+          const uint32_t j0 = first_in_table(hits & window_mask((int32_t)pos0, len));
+          const uint32_t found = j0 < NW ? pos0 + j0 : kNoHit;
+          uint32_t ring = rel;   // the read's word in the first-hit ring
+          if (GROUPS && GRP > 1u) {
+            ring = rel * GRP + g0;
+            rd = ring;           // (what tells two reads apart below)
+            if (g0 + 1u < GRP && pos0 + NW > GS) {
+              const uint32_t j1 = first_in_table(hits & window_mask((int32_t)pos0 - (int32_t)GS, len));
+              if (j1 < NW) __hip_atomic_fetch_min(&lds_fh[(ring + 1u) & FHM], pos0 + j1 - GS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
           // An adapter covers several chunks of its read, and their entries sit next to each other in
@@ -887,7 +961,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           if (found != kNoHit && !covered) keep ^= found + rd;
 #else
           if (found != kNoHit && !covered) {
-            if (fh_ring) __hip_atomic_fetch_min(&lds_fh[rel & (kFhRing - 1u)], found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (fh_ring) __hip_atomic_fetch_min(&lds_fh[ring & FHM], found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else atomicMin(&p.first_hit[rd], found);
           }
 #endif
@@ -917,7 +991,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         if (cand_n) drain_candidates();
         __syncthreads();
         fold_first_hits(it_step);
-      } else if (ADAPT && MODE == 0 && cand_n > kCandCap - 64u) {
+      } else if (ADAPT && MODE == 0 && !W16 && cand_n > kCandCap - 64u) {   // (W16: when a step's entries would not fit, see the push)
         drain_candidates();
       }
 #endif
@@ -1163,6 +1237,14 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             // position cpos-9: the last base of the chunk two chunks back — the previous lane's (W16: its first chunk)
             uint32_t prev2 = 0;
             if constexpr (!W16) prev2 = from_prev_lane(ploU[u][0] >> 16) & 3u;
+            if constexpr (W16) {
+              // (round 4) the queue is checked when the step's entries would not fit any more (kCandCap16)
+#if defined(QK_ABL) && (QK_ABL & 32)
+              if (cand_n + (uint32_t)__builtin_popcountll(pushers) > kCandCap16) cand_n = 0;
+#else
+              if (cand_n + (uint32_t)__builtin_popcountll(pushers) > kCandCap16) drain_candidates();
+#endif
+            }
             if (hits) {
               const uint32_t at = cand_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushers, 0u));
               if constexpr (W16)   // (the words as they stand: own 16 codes; the previous lane's word, of which the drain reads bits 0-17)
@@ -1172,10 +1254,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             }
             cand_n += (uint32_t)__builtin_popcountll(pushers);
 #if defined(QK_ABL) && (QK_ABL & 32)   /* experiment: candidates queued, never checked */
-            if (cand_n > kCandCap - 64u) cand_n = 0;
+            if (!W16 && cand_n > kCandCap - 64u) cand_n = 0;
 #else
             // (room for the next read's entries; behind the last read of a step the check at the start of the next one does)
-            if (u + 1 < U && cand_n > kCandCap - 64u) drain_candidates();
+            if (!W16 && u + 1 < U && cand_n > kCandCap - 64u) drain_candidates();
 #endif
           }
         }

@@ -249,6 +249,7 @@ struct Plan {
   uint32_t bucket_log2, halo, replicas;
   bool fused_adapters, dynamic, aligned, sorted;
   bool w16;   // 16 positions per lane (qk::hist_kernel<..., W16>): dword-aligned batches under the planner's own geometry
+  uint32_t fh_words;   // first-hit ring of the fused adapter path (fixed-length batches): the largest power of two the LDS has room for
 };
 constexpr unsigned kQueueRing = 8;       // queue sets that rotate (launches of one accumulator run in order)
 constexpr unsigned kQueueTiles = 1u << 17;  // counters per launch: reads of up to 64 Mbases (512-position tiles)
@@ -259,6 +260,42 @@ constexpr unsigned kQueueTiles = 1u << 17;  // counters per launch: reads of up 
 // (measured on 300 bp: two 152-wide tiles 1.78 ms, one 304-wide tile 1.10 ms).
 // Longer reads get tiles of <= 512 positions.  The grid is sized to residency:
 // workgroups per CU = what the LDS admits (at most 2 of 1024 threads).
+uint32_t single_tile_cap(const qk_accum *a, bool ragged, bool w16) {
+  uint32_t cap = 576u;
+  while (cap > 64u && qk::hist_lds_bytes(cap / 8, qk::hist_replicas(cap / 8), a->adapters, 0, ragged, qk::kStageReads, w16) > 160 * 1024)
+    cap -= 32u;
+  return cap;
+}
+
+// Grouped rows (qk::HistParams::group): how many consecutive reads of a fixed-length batch — `stride` bytes apart, a
+// multiple of 4 — the fused adapter kernel should take as ONE row of 16-position lanes.  A row of G reads needs
+// ceil(((G - 1) * stride + read_len) / 16) lanes; the G with the fewest lanes per base whose row still fits one tile
+// wins (150 bp at stride 152: 10 lanes for one read, 19 for two; 100 bp: 7 / 19 for three; 36 bp: 3 / 9 for four), 1
+// when nothing is gained.  Only under the planner's own geometry, with the first hits in the LDS ring.
+uint32_t choose_group(const qk_accum *a, uint64_t n_reads, uint32_t read_len, uint32_t stride, bool base_aligned4, uint32_t row_cap = 0) {
+  if (!a->adapters || getenv("QUACK_HIP_UNFUSED_ADAPTERS") || getenv("QUACK_HIP_NO_GROUP") || getenv("QUACK_HIP_NO_W16") ||
+      getenv("QUACK_HIP_NO_ALIGN4") || getenv("QUACK_HIP_SEPARATE_COUNT") || getenv("QUACK_HIP_ADAPT_PD") || getenv("QUACK_HIP_ADAPT_U") ||
+      getenv("QUACK_HIP_W16_U") || getenv("QUACK_HIP_W16_PD"))
+    return 1;
+  if (a->unroll || a->pipe || a->threads != 1024 || a->tile > 0 || a->wgs_per_cu > 0) return 1;
+  if ((stride & 3u) || stride < 16u || read_len < 11u || !base_aligned4) return 1;
+  const uint32_t cap = single_tile_cap(a, false, true);   // positions of the widest one-tile row
+  const int forced = env_int("QUACK_HIP_GROUP", 0);       // (tests: a given group size, where it fits)
+  uint32_t best = 1;
+  double best_cost = 0;
+  for (uint32_t g = 1; g <= 8u && g <= n_reads; ++g) {
+    const uint32_t row = (g - 1u) * stride + read_len;
+    if (g > 1u && ((uint32_t)round_up(row, 16) > cap || (row_cap && row > row_cap))) break;
+    if (g > 1u && (1008u / (uint32_t)(round_up(row, 16) / 16)) * g > qk::kFhRing / 2u) continue;   // reads per step must fit half the ring
+    const double cost = (double)round_up(row, 16) / ((double)g * read_len);
+    if (forced > 0 ? g == (uint32_t)forced : (g == 1u || cost < best_cost * 0.985)) {
+      best = g;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
 int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, bool gapped, bool aligned, Plan *pl,
               bool base_aligned4 = true, bool strided = false, uint32_t addr_stride = 0) {
   const uint32_t T = (uint32_t)a->threads;
@@ -289,9 +326,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
                                   (max_len >= 64 || round_up(max_len, 16) == round_up(max_len, 8))));
   if (getenv("QUACK_HIP_W16_ALWAYS") && !tuned && !strided && !ragged && (fstride & 3u) == 0 && base_aligned4) w16 = true;   // (tests: the plain fixed-length variant)
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
-  uint32_t single_cap = 576u;
-  while (single_cap > 64u && qk::hist_lds_bytes(single_cap / 8, qk::hist_replicas(single_cap / 8), a->adapters, 0, ragged, qk::kStageReads, w16) > 160 * 1024)
-    single_cap -= 32u;
+  const uint32_t single_cap = single_tile_cap(a, ragged, w16);
   uint32_t cap = a->tile > 0 ? std::max<uint32_t>(8, (uint32_t)a->tile / 8 * 8) : single_cap;
   cap = std::min(cap, single_cap);
   uint32_t n_tiles = std::max<uint32_t>(1, (max_len + cap - 1) / cap);
@@ -368,7 +403,23 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
            qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, true, pl->stage_reads * 2, w16) <= 160 * 1024)
       pl->stage_reads *= 2;
   }
-  size_t lds = qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, ragged, pl->stage_reads, w16);
+  // First-hit ring of the fused adapter path (fixed-length batches): the largest power of two the LDS has room for.  Every
+  // fh_words / 2 reads the workgroup folds the ring — every wave checks its queue, however empty, and they meet at a barrier:
+  // 10M x 150 + adapters, same box: 2048 words (a fold every 10 steps) 0.6474 ms, 8192 words 0.6268.  A ring of 8192 words is
+  // worth more than counter replicas (which measure nothing with the adapter scan: 0.6479 against 0.6474 ms): they go first.
+  pl->fh_words = qk::kFhRing;
+  if (pl->fused_adapters && !ragged && !getenv("QUACK_HIP_SMALL_RING")) {
+    const uint32_t most = (uint32_t)std::max(2048, std::min((int)qk::kFhRingMax, env_int("QUACK_HIP_RING_WORDS", (int)qk::kFhRingMax)));
+    auto ring_for = [&](uint32_t replicas) {
+      uint32_t wds = qk::kFhRing;
+      while (wds * 2 <= most && qk::hist_lds_bytes(pl->ch, replicas, true, pl->bucket_log2, false, pl->stage_reads, w16, wds * 2) <= 160 * 1024)
+        wds *= 2;
+      return wds;
+    };
+    while (pl->replicas > 1 && ring_for(pl->replicas) < std::min<uint32_t>(most, 8192u) && !getenv("QUACK_HIP_REPLICAS")) --pl->replicas;
+    pl->fh_words = ring_for(pl->replicas);
+  }
+  size_t lds = qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, ragged, pl->stage_reads, w16, pl->fh_words);
   if (lds > 160 * 1024) return fail(QK_EINVAL, "LDS tile too large (%zu bytes)", lds);
   // residency: the kernels need 89-104 VGPRs, i.e. 4 waves per SIMD = 1024
   // threads per CU, and the LDS image must fit as many times
@@ -550,7 +601,7 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
 
 int launch_hist(qk_accum *a, const qk::HistParams &hp, const Plan &pl, bool fixed, int mode, bool adapt,
                 hipStream_t st, bool strided = false) {
-  const size_t lds = qk::hist_lds_bytes(hp.ch, pl.replicas, adapt, hp.bucket_log2, !fixed, pl.stage_reads, pl.w16);
+  const size_t lds = qk::hist_lds_bytes(hp.ch, pl.replicas, adapt, hp.bucket_log2, !fixed, pl.stage_reads, pl.w16, pl.fh_words);
   dim3 grid((unsigned)pl.n_blocks);
 #define QK_TU(TT, UU, PP) \
   if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, strided, pl.w16, grid, lds, st);
@@ -594,7 +645,7 @@ int order_after_previous(qk_accum *a, hipStream_t st) {
 int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
                   const uint64_t *d_off, uint32_t *d_hit, uint64_t n_reads,
                   uint64_t total_bytes, uint32_t max_len, hipStream_t st,
-                  const uint32_t *d_len = nullptr, uint32_t flags = 0, uint32_t stride = 0) {
+                  const uint32_t *d_len = nullptr, uint32_t flags = 0, uint32_t stride = 0, bool no_group = false) {
   if (n_reads == 0) return QK_OK;
   if (n_reads > 0xFFFFFFF0ull) return fail(QK_EINVAL, "batch too large");
   int rc = grow_table(a, std::max<uint64_t>(max_len, 11));
@@ -610,10 +661,39 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   const bool padded = d_off == nullptr && d_len == nullptr && stride > max_len;
   if (padded && (stride & 3u)) return fail(QK_EINVAL, "a padded stride must be a multiple of 4");
   if (d_off && d_len && total_bytes > 0x7FFFFFF0ull) return fail(QK_EINVAL, "a gapped batch must stay below 2 GiB");
-  rc = make_plan(a, n_reads, strided ? stride : max_len, d_off != nullptr, d_off && d_len,
-                 d_off && d_len && (flags & QK_BATCH_ALIGNED128), &pl, (((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) == 0,
-                 strided, padded ? stride : 0u);
-  if (rc) return rc;
+  const bool base4 = (((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) == 0;
+  // fixed-length reads with the fused adapter scan: rows of several reads where that fills the 16-position lanes better
+  // (qk::HistParams::group); the reads that do not make a whole row run as a small batch of their own
+  uint32_t group = 1;
+  const uint32_t rstride = (strided || padded) ? stride : max_len;   // bytes between two reads of a fixed-stride batch
+  if (!d_off && !d_len && !no_group && n_reads >= 64) {
+    uint32_t row_cap = 0;
+    for (;;) {
+      group = choose_group(a, n_reads, max_len, rstride, base4, row_cap);
+      if (group <= 1) break;
+      const uint32_t row = (group - 1u) * rstride + max_len;
+      rc = make_plan(a, n_reads / group, row, false, false, false, &pl, base4, false, group * rstride);
+      if (rc == QK_OK && pl.w16 && pl.n_tiles == 1 && pl.fused_adapters && (uint64_t)pl.rw * (uint32_t)pl.unroll * group <= qk::kFhRing / 2u &&
+          (pl.bucket_log2 || !a->bucket_log2))
+        break;
+      row_cap = row - 1u;   // (the row does not fit beside the adapter tables after all: a shorter one)
+    }
+  }
+  if (group > 1) {
+    const uint64_t rem = n_reads % group;
+    if (rem) {
+      const uint64_t head = n_reads - rem;
+      rc = enqueue_batch(a, d_seq + head * rstride, d_qual + head * rstride, nullptr, d_hit ? d_hit + head : nullptr, rem, rem * (uint64_t)rstride,
+                         max_len, st, nullptr, 0, stride, /*no_group=*/true);
+      if (rc) return rc;
+      n_reads = head;
+      total_bytes = head * (uint64_t)rstride;
+    }
+  } else {
+    rc = make_plan(a, n_reads, strided ? stride : max_len, d_off != nullptr, d_off && d_len,
+                   d_off && d_len && (flags & QK_BATCH_ALIGNED128), &pl, base4, strided, padded ? stride : 0u);
+    if (rc) return rc;
+  }
   if (strided) {
     // The strided kernel variant exists for the planner's own geometry only.  Under a tuning override
     // (QUACK_HIP_THREADS / _UNROLL / _PIPE / _NO_ALIGN4 / _ADAPT_PD / _ADAPT_U, qk_accum_configure) the same
@@ -650,7 +730,8 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   TimedLaunch tl{};
   // (events around a launch cost ~10 us of stream time: a caller that also measures its own wall
   // clock asks for every Nth batch only)
-  const bool timed = a->timing > 0 && (a->timing_seq++ % (uint64_t)a->timing) == 0;
+  // (the few reads that did not make a whole row of a grouped batch are not a launch of their own to the timing hooks)
+  const bool timed = a->timing > 0 && !no_group && (a->timing_seq++ % (uint64_t)a->timing) == 0;
   if (timed) {
     tl.t0 = get_event(a);
     tl.t1 = get_event(a);
@@ -695,11 +776,14 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.kmer_buckets = a->d_kmer_buckets;
   hp.bucket_log2 = pl.bucket_log2;
   hp.bucket_mul = a->bucket_mul;
-  hp.n_reads = n_reads;
+  hp.n_reads = n_reads / group;   // (rows)
+  hp.fh_words = pl.fh_words;
+  hp.group = group;
+  hp.gstride = rstride;
   hp.total_bytes = total_bytes;
   hp.reads_per_slice = pl.reads_per_slice;
   hp.read_len = d_off ? 0 : (strided ? stride : max_len);
-  hp.stride = d_off ? 0 : ((strided || padded) ? stride : max_len);
+  hp.stride = d_off ? 0 : rstride * group;   // (between rows)
   hp.table_len = (uint32_t)a->table_len;
   hp.n_tiles = pl.n_tiles;
   hp.tile_pos = pl.tile_pos;
@@ -1042,9 +1126,31 @@ int qk_debug_plan(uint64_t n_reads, uint32_t max_len, int ragged, int adapters, 
   if (rc) return rc;
   out[0] = pl.n_tiles; out[1] = pl.tile_pos; out[2] = pl.ch; out[3] = pl.rw;
   out[4] = (uint64_t)pl.unroll; out[5] = (uint64_t)pl.pipe; out[6] = pl.reads_per_slice; out[7] = pl.n_slices;
-  out[8] = pl.n_blocks; out[9] = qk::hist_lds_bytes(pl.ch, pl.replicas, pl.fused_adapters, pl.bucket_log2, ragged != 0, pl.stage_reads, pl.w16);
+  out[8] = pl.n_blocks; out[9] = qk::hist_lds_bytes(pl.ch, pl.replicas, pl.fused_adapters, pl.bucket_log2, ragged != 0, pl.stage_reads, pl.w16, pl.fh_words);
   out[10] = pl.halo; out[11] = pl.fused_adapters; out[12] = pl.dynamic; out[13] = (pl.aligned ? 1u : 0u) | (pl.w16 ? 2u : 0u);
   out[14] = pl.replicas; out[15] = qk::hist_row_dwords(pl.ch, pl.replicas);
+  return QK_OK;
+}
+
+// How a fixed-length batch with the adapter scan would be cut into rows (choose_group + the plan of a row), without a device.
+int qk_debug_group(uint64_t n_reads, uint32_t read_len, uint32_t stride, uint32_t bucket_log2, uint64_t *out /* [8] */) {
+  if (!out) return fail(QK_EINVAL, "out is NULL");
+  qk_accum a;
+  a.adapters = true;
+  a.bucket_log2 = bucket_log2;
+  uint32_t group = 1, row_cap = 0;
+  Plan pl;
+  for (;;) {
+    group = choose_group(&a, n_reads, read_len, stride, true, row_cap);
+    const uint32_t row = (group - 1u) * stride + read_len;
+    int rc = make_plan(&a, n_reads / group, row, false, false, false, &pl, true, false, group * stride);
+    if (rc) return rc;
+    if (group <= 1 || (pl.w16 && pl.n_tiles == 1 && (uint64_t)pl.rw * (uint32_t)pl.unroll * group <= qk::kFhRing / 2u && (pl.bucket_log2 || !a.bucket_log2)))
+      break;
+    row_cap = row - 1u;
+  }
+  out[0] = group; out[1] = (group - 1u) * stride + read_len; out[2] = pl.tile_pos; out[3] = pl.rw; out[4] = (uint64_t)pl.unroll;
+  out[5] = pl.w16; out[6] = pl.bucket_log2; out[7] = qk::hist_lds_bytes(pl.ch, pl.replicas, pl.fused_adapters, pl.bucket_log2, false, pl.stage_reads, pl.w16, pl.fh_words);
   return QK_OK;
 }
 

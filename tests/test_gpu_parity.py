@@ -156,6 +156,72 @@ def test_padded_fixed_length_every_length(adapters, monkeypatch):
     assert not adapters or hits > 1000
 
 
+@pytest.mark.parametrize("forced", [None, "1", "2", "3", "4", "5", "8"])
+def test_grouped_rows_every_group_size(forced, monkeypatch):
+    """round 4: with the adapter scan a ROW of the fixed-length kernel is several consecutive reads (two 150 bp reads 152
+    bytes apart fill 19 lanes of 16 positions where one fills 10 with 6 % idle; three of 100 bp; four of 36 bp): the flush
+    folds the column groups, the candidate check splits a lane's windows between the two reads it may straddle, the first-hit
+    ring holds a word per read.  Every group size that fits (QUACK_HIP_GROUP) and the planner's own choice, read counts that
+    leave a remainder, adapters at every offset of every read of a row (hits at position 9, at the last base, across the
+    seam between two reads — which must not count), packed and padded strides; and QUACK_HIP_NO_GROUP agrees"""
+    import torch
+    if forced:
+        monkeypatch.setenv("QUACK_HIP_GROUP", forced)
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    bits = ob.kmers_to_bitset(k)
+    hits = 0
+    for L in (11, 16, 17, 20, 31, 36, 40, 50, 64, 75, 76, 100, 101, 125, 148, 149, 150, 151, 152, 160, 250, 300):
+        n = 3001 if L <= 160 else 803               # (odd: a remainder for every group size but 1)
+        seq, qual = synth.fixed(n, L, seed=1000 + L, q_lo=0, q_hi=60)
+        seq = seq.copy().reshape(n, L)
+        for r in range(n):                          # an adapter in two reads out of three, every offset, also cut off by the read's end
+            if r % 3 == 2:
+                continue
+            ad = np.frombuffer(ads[r % len(ads)], np.uint8)
+            at = (r // 3 * 7 + r) % max(1, L - 9) if r % 3 == 0 else max(0, L - 10 - (r // 3) % 12)
+            m = min(len(ad), L - at)
+            seq[r, at:at + m] = ad[:m]
+        # ... a false candidate right in front of a true adapter (nine bases of an adapter and a wrong tenth: passes the 9-mer
+        # filter, is in no table), so that the lane of the true first hit stands behind a lane that confirms nothing
+        if L >= 60:
+            for r in range(2, n, 3):
+                ad = np.frombuffer(ads[(r + 2) % len(ads)], np.uint8)
+                at = (r * 5) % (L - 45)
+                seq[r, at:at + 9] = ad[:9]
+                seq[r, at + 9] = ord("A") if ad[9] != ord("A") else ord("C")
+                gap = 10 + (r // 3) % 20
+                m = min(len(ad), L - at - gap)
+                seq[r, at + gap:at + gap + m] = ad[:m]
+        # ... and adapter 10-mers that only exist ACROSS the seam of two neighbouring reads (never a hit)
+        for r in range(1, n, 5):
+            ad = np.frombuffer(ads[(r + 1) % len(ads)], np.uint8)
+            cut = 1 + r % 9
+            if L > 30:
+                seq[r - 1, L - cut:] = ad[:cut]
+                seq[r, :10 - cut] = ad[cut:10]
+        seq = seq.reshape(-1)
+        want = ob.accumulate_batch(seq, qual, read_len=L, kmers=k)
+        hits += int(want[0][:, 96].sum())
+        stride = (L + 3) & ~3
+        s2, q2 = padded_layout(seq, qual, n, L, stride, seed=L)
+        for env in ({}, {"QUACK_HIP_NO_GROUP": "1"}, {"QUACK_HIP_SMALL_RING": "1"}) if forced is None else ({},):
+            for kk, v in env.items():
+                monkeypatch.setenv(kk, v)
+            with quack_amd.Accumulator(0, bits) as acc:
+                d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+                acc.submit_device_padded(d_s, d_q, n, L, stride)
+                acc.submit_fixed(seq, qual, L)
+                sd = acc.finish()
+            for kk in env:
+                monkeypatch.delenv(kk)
+            try:
+                assert_same((sd.bases, sd.number_of_sequences), (2 * want[0], 2 * n))
+            except AssertionError as e:
+                raise AssertionError("read length %d, %s: %s" % (L, env, e))
+    assert hits > 5000
+
+
 def test_padded_batches_through_the_pinned_slots_and_under_overrides(monkeypatch):
     """qk_accum_acquire / qk_accum_commit_padded (what the host feed drives), several batches with table growth in
     between; and the padded form under tuning overrides, where the 12-byte-window kernels take the stride as it is"""

@@ -24,6 +24,8 @@ def main():
                     "where an accumulator's buffers land is worth up to 2 %% on some boxes")
     ap.add_argument("--dummy-streams", type=int, default=0, help="streams created (and kept) before the first accumulator")
     ap.add_argument("--dummy-mb", type=int, default=0, help="device memory allocated (and kept) before the first accumulator")
+    ap.add_argument("--splice", type=float, default=None, help="share of the reads that carry a spliced adapter (adapter workloads)")
+    ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("settings", nargs="*")
     a = ap.parse_args()
     settings = [("" if s == "-" else s) for s in a.settings] or ["", ""]
@@ -32,6 +34,12 @@ def main():
     import bench
     import quack_amd
     w = dict(bench.WORKLOADS[a.workload])
+    if a.splice is not None:
+        w["splice"] = a.splice
+    if a.read_len:
+        w["L"] = a.read_len
+        if w.get("pad"):
+            w["pad"] = (a.read_len + 3) & ~3
     ads_bits, ads = bench.synthetic_adapter_bits(np) if w["adapters"] else (None, None)
     b = bench.make_batch(torch, np, w, seed={"cfg3": 3, "cfg5": 6, "trimmed": 7}.get(a.workload, 2), device="cuda:0", quality="uniform", ads=ads)
     job = bench.Job.__new__(bench.Job)

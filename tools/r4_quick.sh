@@ -1,14 +1,17 @@
 #!/bin/bash
-# round 4: the padded layout against the packed one, same box (tests first)
+# round 4: quick GPU check — selected tests, then A/B bench lines (args: test filter)
 set -o pipefail
 mkdir -p gpurun_out
 ( time python -c "import torch; print(torch.__version__)" ) > gpurun_out/r4_quick_import.log 2>&1   # (a fresh box pages the image in: minutes, once)
 B="--steps 50 --warmup 100 --no-also --no-cpu-baseline --no-tiers --no-traffic --no-steady"
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -v -x -k "padded or sixteen or adapters_fixed or chunk_count or strided" > gpurun_out/r4_quick_tests.log 2>&1 || { tail -30 gpurun_out/r4_quick_tests.log; exit 1; }
+timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -v -x -k "${1:-padded or grouped}" > gpurun_out/r4_quick_tests.log 2>&1 || { tail -40 gpurun_out/r4_quick_tests.log; exit 1; }
 tail -3 gpurun_out/r4_quick_tests.log
-for w in cfg3_150 cfg3_150packed cfg3_150 cfg3_150packed cfg2 cfg2pad cfg2 cfg2pad cfg3; do
-  echo "== $w" >> gpurun_out/r4_quick_bench.log
-  timeout -k 10 300 python bench.py --workload $w $B >> gpurun_out/r4_quick_bench.log 2>gpurun_out/r4_quick_err.log || { tail -20 gpurun_out/r4_quick_err.log; exit 1; }
+rm -f gpurun_out/r4_quick_bench.log
+for w in ${2:-cfg3_150 cfg3_150packed cfg3}; do
+  for e in "" ${3:-QUACK_HIP_NO_GROUP=1}; do
+  echo "== $w $e" >> gpurun_out/r4_quick_bench.log
+  env $e timeout -k 10 300 python bench.py --workload $w $B $4 >> gpurun_out/r4_quick_bench.log 2>gpurun_out/r4_quick_err.log || { tail -20 gpurun_out/r4_quick_err.log; exit 1; }
+  done
 done
 python - <<'PY'
 import json
