@@ -214,6 +214,7 @@ def make_batch(torch, np, w, seed, device, quality="uniform", q_hi_override=None
             ok = (at + j < L) & (j < alen[which])
             seq[(pick * S + at + j)[ok]] = tab[which[ok], j]
         spliced = int(len(pick))
+    torch.cuda.synchronize(device)   # (made on torch's stream; the accumulators launch on their own streams, which wait for nobody)
     return dict(seq=seq, qual=qual, d_off=d_off, d_len=d_len, total=total, max_len=max_len, extent=extent,
                 n=w["n"], spliced=spliced, stride=w.get("stride") if w["ragged"] else None,
                 pad=w.get("pad") if not w["ragged"] else None)

@@ -28,6 +28,7 @@ def device_fixed(n, L, seed, q_lo=2, q_hi=41):
 
 
 def run_device(seq, qual, off, n, total, max_len, bits=None, passes=1):
+    torch.cuda.synchronize()     # (the batch was made on torch's stream; the accumulator's own stream waits for nobody)
     with quack_amd.Accumulator(0, bits) as acc:
         for _ in range(passes):
             acc.submit_device(seq, qual, off, n, total, max_len)
@@ -76,12 +77,41 @@ def test_config3_10M_x_300_adapters_exact_on_every_read():
     np.testing.assert_array_equal(sd.bases, want)
 
 
+def test_config3_at_150bp_padded_exact_on_every_read(monkeypatch):
+    """the metric's own read length on config 3's path (round 4): the bench's cfg3_150 batch — 10M x 150 + adapters, 25 % of
+    the reads spliced, reads 152 bytes apart as the host feed lays them out — every counter against the oracle over ALL
+    reads; and the same reads as single-read rows (QUACK_HIP_NO_GROUP) and with the smallest first-hit ring"""
+    import bench
+    w = dict(bench.WORKLOADS["cfg3_150"])
+    n, L, S = w["n"], w["L"], w["pad"]
+    bits, ads = bench.synthetic_adapter_bits(np)
+    k = ob.kmers_from_seqs([bytes(a) for a in ads])
+    b = bench.make_batch(torch, np, w, seed=5, device=torch.device("cuda", 0), ads=ads)
+    assert 0.2 * n < b["spliced"] < 0.3 * n and b["pad"] == S
+    hs, hq, off, m, bases = bench.host_sample(np, b, w, 1 << 62)
+    assert off is None and m == n and bases == n * L
+    want, wn = ob.accumulate_batch_threads(hs, hq, read_len=L, kmers=k)
+    assert wn == n and 0.2 * n < want[:, 96].sum() <= n
+    torch.cuda.synchronize()
+    for env in ({}, {"QUACK_HIP_NO_GROUP": "1"}, {"QUACK_HIP_SMALL_RING": "1"}):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        with quack_amd.Accumulator(0, bits) as acc:
+            acc.submit_device_padded(b["seq"], b["qual"], n, L, S)
+            sd = acc.finish()
+        for kk in env:
+            monkeypatch.delenv(kk)
+        assert sd.number_of_sequences == n and sd.max_length == L, env
+        np.testing.assert_array_equal(sd.bases, want, err_msg=str(env))
+
+
 def test_trimmed_10M_strided_exact_on_every_read():
     """the bench's trimmed-reads batch (70 % full length, the rest 120-149, stride 152 + lengths[]) against the
     oracle on the same reads packed"""
     import bench
     w = dict(bench.WORKLOADS["trimmed"])
     b = bench.make_batch(torch, np, w, seed=7, device=torch.device("cuda", 0))
+    torch.cuda.synchronize()
     with quack_amd.Accumulator(0) as acc:
         acc.submit_device_strided(b["seq"], b["qual"], b["d_len"], b["n"], b["stride"], b["max_len"])
         sd = acc.finish()
@@ -103,6 +133,7 @@ def test_config4_full_per_gpu_share_each_mate_exact():
     f = bench.make_batch(torch, np, w, seed=4, device=dev)
     r = bench.make_batch(torch, np, w, seed=5, device=dev, q_hi_override=30)
     side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
     with quack_amd.Accumulator(0, None, max_len_hint=L) as fa, quack_amd.Accumulator(0, None, max_len_hint=L) as ra:
         for _ in range(3):
             fa.submit_device(f["seq"], f["qual"], None, n, n * L, L, stream=side.cuda_stream)

@@ -16,12 +16,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=120)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--rounds", type=int, default=1 << 30)
-    a = ap.parse_args()
+def fuzz(seconds, seed, rounds=1 << 30, log=print):
+    """-> (rounds done, None) or (rounds done, description of the first mismatch); tests/test_gpu_fuzz.py runs a
+    seeded, time-boxed stretch of it inside the -m gpu suite"""
+    import types
+    a = types.SimpleNamespace(seconds=seconds, seed=seed, rounds=rounds)
     import torch
     import oracle_binding as ob
     import synth
@@ -76,7 +75,15 @@ def main():
             route = int(rng.integers(0, 3))
             if family == "fixed":
                 L = int(lens[0])
-                if route == 0 or (L & 3):
+                if route == 2 and (L & 3):
+                    stride = (L + 3) & ~3
+                    how = "submit_device_padded stride %d" % stride
+                    s2 = np.full((n, stride), ord("C"), np.uint8)
+                    q2 = np.full((n, stride), 50, np.uint8)
+                    s2[:, :L], q2[:, :L] = seq.reshape(n, L), qual.reshape(n, L)
+                    d_s, d_q = torch.from_numpy(pad_for_device(s2.reshape(-1))).cuda(), torch.from_numpy(pad_for_device(q2.reshape(-1))).cuda()
+                    acc.submit_device_padded(d_s, d_q, n, L, stride)
+                elif route == 0 or (L & 3):
                     how = "submit_fixed x%d" % (1 + route)
                     cut = [n * i // (1 + route) for i in range(2 + route)]
                     for x, y in zip(cut, cut[1:]):
@@ -115,16 +122,29 @@ def main():
             sd = acc.finish()
         ok = sd.number_of_sequences == want[1] and sd.bases.shape == want[0].shape and np.array_equal(sd.bases, want[0])
         if not ok:
-            print("MISMATCH seed %d: %s n=%d lens %d..%d adapters=%s alphabet=%d via %s" % (seed, family, n, lens.min(), lens.max(), adapters, len(alphabet), how), flush=True)
+            msg = "MISMATCH seed %d: %s n=%d lens %d..%d adapters=%s alphabet=%d via %s" % (seed, family, n, lens.min(), lens.max(), adapters, len(alphabet), how)
             if sd.bases.shape == want[0].shape:
                 pos, row = np.argwhere(sd.bases != want[0])[0]
-                print("  first at position %d row %d: hip %d oracle %d (%d cells)" % (pos, row, sd.bases[pos, row], want[0][pos, row], (sd.bases != want[0]).sum()))
-            sys.exit(1)
+                msg += "; first at position %d row %d: hip %d oracle %d (%d cells)" % (pos, row, sd.bases[pos, row], want[0][pos, row], (sd.bases != want[0]).sum())
+            return done, msg
         done += 1
         seed += 1
         if done % 20 == 0:
-            print("%d rounds ok (last: %s n=%d via %s)" % (done, family, n, how), flush=True)
-    print("fuzz: %d rounds, all equal to the oracle (seeds %d..%d)" % (done, a.seed, seed - 1))
+            log("%d rounds ok (last: %s n=%d via %s)" % (done, family, n, how))
+    return done, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--rounds", type=int, default=1 << 30)
+    a = ap.parse_args()
+    done, bad = fuzz(a.seconds, a.seed, a.rounds, log=lambda m: print(m, flush=True))
+    if bad:
+        print(bad, flush=True)
+        sys.exit(1)
+    print("fuzz: %d rounds, all equal to the oracle (seeds %d..%d)" % (done, a.seed, a.seed + done - 1))
 
 
 if __name__ == "__main__":
