@@ -103,7 +103,8 @@ def parse_args():
     ap.add_argument("--no-traffic", action="store_true",
                     help="N=1: do not measure roofline.traffic in this run (two short child passes under rocprofv3 --pmc); "
                          "the line then carries the builder-run figure of profiles/hbm_traffic.json, labelled so")
-    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end tier's .fq.gz (x 150 bp)")
+    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end tier's small .fq.gz (x 150 bp; the `sustained` loop)")
+    ap.add_argument("--e2e-scale", type=float, default=1.0, help="scale the read counts of the end-to-end tier's config 2 / 3 / 5 files (rehearsals)")
     ap.add_argument("--also-steps", type=int, default=50)
     ap.add_argument("--also-warmup", type=int, default=100,
                     help="untimed passes in front of each `also` workload's timed ones: past the ~35 ms power transient of a kernel's first launches")
@@ -474,6 +475,84 @@ def gather_ranks(ctx, r):
              "ms_per_step": round(float(x[1].item()), 4)} for i, x in enumerate(allr)]
 
 
+def parity_batches(np, rank, ads):
+    """the small batches rank `rank` accumulates in the multi-GPU correctness run: a ragged one whose longest read differs
+    from rank to rank (the exchange has to agree on a geometry first: all-reduce(MAX)), and a fixed-length 150 bp one (the
+    padded / grouped adapter kernel); an adapter spliced into every third read.  Deterministic: rank 0 rebuilds every
+    rank's reads for the oracle."""
+    rng = np.random.default_rng(7000 + rank)
+    acgtn = np.frombuffer(b"ACGTN", np.uint8)
+    n = 3000 + 400 * rank
+    lens = rng.integers(1, 120 + 37 * rank + 1, n)
+    lens[rng.integers(0, n)] = 120 + 37 * rank          # the longest read of this rank is there for certain
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    seq = acgtn[rng.integers(0, 5, int(off[-1]))].copy()
+    qual = (33 + rng.integers(0, 60, int(off[-1]))).astype(np.uint8)
+    for r in range(0, n, 3):
+        a, e = int(off[r]), int(off[r + 1])
+        if e - a > 14:
+            ad = ads[r % len(ads)]
+            at = a + int(rng.integers(0, e - a - 10))
+            m = min(len(ad), e - at)
+            seq[at:at + m] = ad[:m]
+    nf, L = 2001 + rank, 150
+    fseq = acgtn[rng.integers(0, 4, nf * L)].copy()
+    fqual = (33 + rng.integers(2, 42, nf * L)).astype(np.uint8)
+    for r in range(0, nf, 3):
+        ad = ads[(r + rank) % len(ads)]
+        at = int(rng.integers(0, L - 10))
+        m = min(len(ad), L - at)
+        fseq[r * L + at:r * L + at + m] = ad[:m]
+    return (seq, qual, off), (fseq, fqual, L)
+
+
+def multi_gpu_parity_check(ctx):
+    """N > 1, before anything is timed: the first run on several devices is a correctness run.  Every rank accumulates ITS
+    OWN small batches (parity_batches: different reads, different longest read, adapters) on its device, the path's one
+    exchange runs once (all-reduce(MAX) of the geometry + all-reduce(SUM) of the tables: RCCL, or gloo in a rehearsal), and
+    every rank compares what it then holds with the oracle over the union of all ranks' reads (quack.c:911-921, 202-220:
+    commutative ++).  -> the dict that goes into the line as ranks.parity_check; a mismatch ends the run with rc != 0."""
+    np, torch, dist, quack_amd, qd, args = ctx["np"], ctx["torch"], ctx["dist"], ctx["quack_amd"], ctx["qd"], ctx["args"]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob     # (the checker; nothing of it is measured)
+    bits, ads = synthetic_adapter_bits(np)
+    kmers = ob.kmers_from_seqs([bytes(a) for a in ads])
+    (seq, qual, off), (fseq, fqual, L) = parity_batches(np, ctx["rank"], ads)
+    t0 = time.perf_counter()
+    with quack_amd.Accumulator(ctx["local"], bits) as acc:
+        acc.submit(seq, qual, off)
+        acc.submit_fixed(fseq, fqual, L)
+        my_longest = acc.stats()[0]
+        qd.allreduce_accumulators([acc], via_host=args.backend == "gloo")
+        sd = acc.finish()
+    dt = time.perf_counter() - t0
+    want, reads = None, 0
+    for r in range(ctx["world"]):
+        (s, q, o), (fs, fq, fl) = parity_batches(np, r, ads)
+        for tab, n in (ob.accumulate_batch(s, q, o, kmers=kmers), ob.accumulate_batch(fs, fq, read_len=fl, kmers=kmers)):
+            if want is None or tab.shape[0] > want.shape[0]:
+                grown = np.zeros((tab.shape[0], 97), np.uint64)
+                if want is not None:
+                    grown[:want.shape[0]] = want
+                want = grown
+            want[:tab.shape[0]] += tab
+            reads += n
+    ok = sd.number_of_sequences == reads and sd.bases.shape == want.shape and bool(np.array_equal(sd.bases, want))
+    cd = ctx["device"] if args.backend == "nccl" else "cpu"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cd)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    res = {"ok": bool(flag.item()), "reads": reads, "max_length": int(sd.max_length), "longest_read_of_rank0": int(my_longest),
+           "kmer_hits": int(want[:, 96].sum()), "seconds": round(dt, 3),
+           "what": "every rank accumulated its own ragged + 150 bp batches with adapters (longest read 120 + 37 x rank), one exchange, every "
+                   "rank's table == the oracle over the union of all ranks' reads (all cells; the MIN over ranks of the verdicts)"}
+    if not ok:
+        sys.stderr.write("bench.py: rank %d: the exchanged table differs from the oracle over all ranks' reads (%d vs %d reads)\n"
+                         % (ctx["rank"], sd.number_of_sequences, reads))
+    if not res["ok"]:
+        raise SystemExit("multi-GPU parity check failed")
+    return res
+
+
 # --------------------------------------------------------------------------
 _traffic_broken = None   # why a child pass failed: no further pass is attempted in this run (a hung profiler must not cost minutes)
 
@@ -560,66 +639,158 @@ def tier_h2d(ctx, n_batches=48):
             "what": "pinned double buffer -> hipMemcpyAsync -> kernels (qk_accum_acquire/commit), 150 bp fixed-length batches"}
 
 
-def tier_end_to_end(ctx, n_reads):
-    """(iii) end-to-end CLI: `quack -u reads.fq.gz > svg` on a gzip file made here (tools/gen_fastq pieces, concatenated
-    members, level 6), wall clock of the whole process; the oracle CLI on the same file as the CPU figure"""
+def _gen_file(d, name, n_reads, lo, hi, seed, extra=()):
+    """a .fq.gz of n_reads made by up to 16 tools/gen_fastq processes (one gzip member each, level 6), concatenated;
+    -> (path, path of the first member alone, reads, reads of the first member, seconds) or None"""
     import shutil
-    import tempfile
-    gen, quack = os.path.join(ROOT, "tools", "gen_fastq"), os.path.join(ROOT, "quack_amd", "host", "quack")
-    oracle = os.path.join(ROOT, "oracle", "_build", "quack_oracle")
-    if not (os.path.exists(gen) and os.path.exists(quack)):
-        return {"skipped": "tools/gen_fastq or quack_amd/host/quack not built"}
+    gen = os.path.join(ROOT, "tools", "gen_fastq")
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    pieces = max(1, min(16, cores, n_reads // 50_000))
-    d = tempfile.mkdtemp(prefix="quack_e2e_")
+    pieces = max(1, min(16, cores, n_reads // 5_000))
+    per = n_reads // pieces
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([gen, os.path.join(d, "%s.p%d.fq.gz" % (name, i)), str(per), str(lo), str(hi), str(seed + i), "2", "41"] + list(extra))
+             for i in range(pieces)]
     try:
-        t0 = time.perf_counter()
-        per = n_reads // pieces
-        procs = [subprocess.Popen([gen, os.path.join(d, "p%d.fq.gz" % i), str(per), "150", "150", str(2000 + i)]) for i in range(pieces)]
-        try:
-            if any(p.wait(timeout=240) != 0 for p in procs):
-                return {"skipped": "gen_fastq failed"}
-        except subprocess.TimeoutExpired:
-            for p in procs:
-                p.kill()
-            return {"skipped": "gen_fastq took too long"}
-        path = os.path.join(d, "e2e.fq.gz")
-        with open(path, "wb") as out:
-            for i in range(pieces):
-                with open(os.path.join(d, "p%d.fq.gz" % i), "rb") as f:
-                    shutil.copyfileobj(f, out, 1 << 24)
-                os.unlink(os.path.join(d, "p%d.fq.gz" % i))
-        t_gen = time.perf_counter() - t0
-        bases = per * pieces * 150
+        if any(p.wait(timeout=240) != 0 for p in procs):
+            return None
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        return None
+    path = os.path.join(d, name + ".fq.gz")
+    first = os.path.join(d, name + ".first.fq.gz")
+    with open(path, "wb") as out:
+        for i in range(pieces):
+            pp = os.path.join(d, "%s.p%d.fq.gz" % (name, i))
+            with open(pp, "rb") as f:
+                shutil.copyfileobj(f, out, 1 << 24)
+            if i == 0:
+                os.replace(pp, first)
+            else:
+                os.unlink(pp)
+    return path, first, per * pieces, per, time.perf_counter() - t0, pieces
+
+
+def _e2e_entry(ctx, d, name, n_reads, lo, hi, seed, adapters_fa=None, splice=0.0, runs=3):
+    """`quack -u file.fq.gz [-a adapters.fa] > svg` on one of BASELINE's files made here: wall clock of the whole process, best and
+    all; the counters of the file's first gzip member (1/16 of the reads) through the same host feed + HIP path against the
+    oracle on that member, every cell; the whole file's counters through size-independent properties; the oracle timed on the
+    first member = the CPU figure"""
+    import shutil
+    np, quack_amd = ctx["np"], ctx["quack_amd"]
+    quack = os.path.join(ROOT, "quack_amd", "host", "quack")
+    free = shutil.disk_usage(d).free
+    need = n_reads * (lo + hi) * 0.6 + (1 << 30)      # ~1.15 bytes of .gz per base
+    if free < need:
+        return {"skipped": "%.1f GB free in %s, the file needs ~%.1f" % (free / 1e9, d, need / 1e9)}
+    made = _gen_file(d, name, n_reads, lo, hi, seed, extra=([adapters_fa, str(splice)] if adapters_fa else []))
+    if made is None:
+        return {"skipped": "gen_fastq failed or took too long"}
+    path, first, reads, first_reads, t_gen, pieces = made
+    try:
         env = dict(os.environ)
         env.pop("QUACK_DEVICES", None)
+        argv = [quack, "-u", path] + (["-a", adapters_fa] if adapters_fa else [])
         walls, svg_len = [], 0
-        for _ in range(3):
+        for _ in range(runs):
             t0 = time.perf_counter()
             try:
-                r = subprocess.run([quack, "-u", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=180)
+                r = subprocess.run(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=180)
             except subprocess.TimeoutExpired:
                 return {"skipped": "quack took more than 180 s"}
             walls.append(time.perf_counter() - t0)
             if r.returncode != 0 or not r.stdout.startswith(b"<svg"):
                 return {"skipped": "quack failed: %s" % r.stderr[-200:].decode(errors="replace")}
             svg_len = len(r.stdout)
-        out = {"value": bases / min(walls), "unit": "bases/s", "wall_s": [round(x, 3) for x in walls], "best_wall_s": round(min(walls), 3),
-               "reads": per * pieces, "bases": bases, "file_bytes": os.path.getsize(path), "svg_bytes": svg_len,
-               "file": "%d gzip members (level 6) of %d reads x 150 bp, made in %.1f s by %d gen_fastq processes" % (pieces, per, t_gen, pieces),
-               "decoder_threads": os.environ.get("QUACK_THREADS", "default: host cores / GPUs of the node, at most 32"),
-               "what": "quack -u file.fq.gz > svg: process start to exit (inflate + tokenize on host threads, pinned double buffer, kernels, "
-                       "transform, draw); the accumulation runs in a worker process, whose own exit (0.13 s of driver teardown) nobody waits for"}
-        if os.path.exists(oracle) and not ctx["args"].no_cpu_baseline:
+        # counters: the whole file through the Python mirror of read_fastq (same host feed, same kernels) ...
+        kmers = quack_amd.read_adapters(adapters_fa) if adapters_fa else None
+        t0 = time.perf_counter()
+        sd = quack_amd.read_fastq(path, kmers)
+        t_lib = time.perf_counter() - t0
+        bases = int(sd.bases[:, 91:95].sum())
+        props = (sd.number_of_sequences == reads and int(sd.bases[:, :91].sum()) == bases and int(sd.bases[:, 95].sum()) == reads
+                 and lo * reads <= bases <= hi * reads and sd.max_length <= hi)
+        out = {"value": bases / min(walls), "unit": "bases/s", "Gbases_per_s": round(bases / min(walls) / 1e9, 3),
+               "wall_s": [round(x, 3) for x in walls], "best_wall_s": round(min(walls), 3),
+               "reads": reads, "bases": bases, "file_bytes": os.path.getsize(path), "svg_bytes": svg_len,
+               "command": "quack -u %s.fq.gz%s" % (name, " -a adapters.fa" if adapters_fa else ""),
+               "file": "%d gzip members (level 6) of %d reads x %s bp%s, made in %.1f s by %d gen_fastq processes" % (
+                   pieces, first_reads, lo if lo == hi else "%d-%d" % (lo, hi), ", %g of them with a spliced adapter" % splice if adapters_fa else "",
+                   t_gen, pieces),
+               "read_fastq_in_process_s": round(t_lib, 3),
+               "counters_whole_file": {"ok": bool(props), "how": "number_of_sequences, one score / one content bin / one length per base and read"}}
+        if not ctx["args"].no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as ob
+            ok_kmers = ob.kmers_from_file(adapters_fa) if adapters_fa else None
             t0 = time.perf_counter()
+            want, wn = ob.read_fastq(first, ok_kmers)
+            t_or = time.perf_counter() - t0
+            got = quack_amd.read_fastq(first, kmers)
+            exact = got.number_of_sequences == wn and got.bases.shape == want.shape and bool(np.array_equal(got.bases, want))
+            fb = int(want[:, 91:95].sum())
+            out["counters_first_member"] = {"ok": bool(exact), "reads": wn, "how": "every cell of the table of the file's first gzip member, HIP path vs oracle"}
+            out["cpu_baseline"] = {"value": fb / t_or, "unit": "bases/s", "cores": 1, "kind": "port", "seconds": round(t_or, 3),
+                                   "sample": "the file's first gzip member (%d reads, %d bases): zlib gzread + the restated loop" % (wn, fb)}
+            if not exact:
+                raise SystemExit("end-to-end tier: the counters of %s differ from the oracle's" % name)
+        if not props:
+            raise SystemExit("end-to-end tier: the counters of %s do not add up" % name)
+        return out
+    finally:
+        for f in (path, first):
             try:
-                r = subprocess.run([oracle, "time", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-            except subprocess.TimeoutExpired:
-                r = None
-            w_or = time.perf_counter() - t0
-            if r is not None and r.returncode == 0:
-                out["cpu_baseline"] = {"value": bases / w_or, "unit": "bases/s", "cores": 1, "kind": "port", "wall_s": round(w_or, 3),
-                                       "sample": "the same file, whole (oracle/oracle_cli.c: zlib gzread + the restated loop, no drawing)"}
+                os.unlink(f)
+            except OSError:
+                pass
+
+
+def tier_end_to_end(ctx, n_reads):
+    """(iii) end-to-end CLI on files made on the spot (tools/gen_fastq): BASELINE's configurations 2, 3 and 5 as .fq.gz
+    (quack.c:858-928 is the flow), and `sustained`: the 4M x 150 bp file eight times in a row, as a shell loop over many
+    files runs (the reference's own usage, images/makefile:8-18) — with the accumulation in a worker process (the default)
+    and in one process (QUACK_NO_FORK=1: the process's exit then includes the HIP runtime's teardown)"""
+    import shutil
+    import tempfile
+    gen, quack = os.path.join(ROOT, "tools", "gen_fastq"), os.path.join(ROOT, "quack_amd", "host", "quack")
+    if not (os.path.exists(gen) and os.path.exists(quack)):
+        return {"skipped": "tools/gen_fastq or quack_amd/host/quack not built"}
+    d = tempfile.mkdtemp(prefix="quack_e2e_")
+    try:
+        np = ctx["np"]
+        out = {"what": "process start to exit of `quack` on a .fq.gz: inflate + tokenize on host threads, pinned double buffer, kernels, "
+                       "transform, draw; the accumulation runs in a worker process, whose own exit (0.13 s of driver teardown) nobody waits for",
+               "decoder_threads": os.environ.get("QUACK_THREADS", "default: host cores / GPUs of the node, at most 32")}
+        # the adapter FASTA of config 3: the bench's 24 synthetic adapters
+        _, ads = synthetic_adapter_bits(np)
+        fa = os.path.join(d, "adapters.fa")
+        with open(fa, "w") as f:
+            for i, a in enumerate(ads):
+                f.write(">adapter%d\n%s\n" % (i, bytes(a).decode()))
+        scale = ctx["args"].e2e_scale
+        out["config2"] = _e2e_entry(ctx, d, "config2", int(10_000_000 * scale), 150, 150, 2000)
+        out["config3"] = _e2e_entry(ctx, d, "config3", int(10_000_000 * scale), 300, 300, 3000, adapters_fa=fa, splice=0.25)
+        out["config5"] = _e2e_entry(ctx, d, "config5", int(143_000 * scale), 1000, 20000, 5000)
+        # sustained: eight runs back to back on the 4M-read file, total wall / 8
+        made = _gen_file(d, "small", n_reads, 150, 150, 2100)
+        if made is not None:
+            path, first, reads, _, t_gen, pieces = made
+            env = dict(os.environ)
+            env.pop("QUACK_DEVICES", None)
+            sus = {"file": "%d reads x 150 bp (%d bytes), %d gzip members" % (reads, os.path.getsize(path), pieces), "runs": 8}
+            for key, extra in (("worker_process", {}), ("one_process", {"QUACK_NO_FORK": "1"})):
+                t0 = time.perf_counter()
+                r = subprocess.run(["/bin/sh", "-c", "for i in 1 2 3 4 5 6 7 8; do %s -u %s > /dev/null || exit 1; done" % (quack, path)],
+                                   env=dict(env, **extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+                wall = time.perf_counter() - t0
+                sus[key] = ({"total_wall_s": round(wall, 3), "wall_per_file_s": round(wall / 8, 4), "Gbases_per_s": round(reads * 150 * 8 / wall / 1e9, 3)}
+                            if r.returncode == 0 else {"failed": r.stderr[-200:].decode(errors="replace")})
+            sus["what"] = ("`for i in 1..8; do quack -u file.fq.gz > /dev/null; done` in one shell: what a loop over many files sustains, the worker's "
+                           "teardown overlapping the next run's start-up; one_process = QUACK_NO_FORK=1 (every exit waits for the HIP runtime)")
+            out["sustained"] = sus
+        best = out["config2"]
+        if "value" in best:
+            out["value"], out["unit"] = best["value"], "bases/s"
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -686,6 +857,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    parity = multi_gpu_parity_check(ctx) if world > 1 else None   # (before anything is timed; a mismatch ends the run, rc != 0)
     res = job.run(args.steps, args.warmup, world=world, exchange=world > 1)
     per_rank = gather_ranks(ctx, res) if world > 1 else None
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -720,7 +892,7 @@ def main():
                             "device_name": torch.cuda.get_device_name(local),
                             "exchange": "one all-reduce(MAX) of %d geometry words + ONE all-reduce(SUM, u64) of %d x %d table words, inside the timed region" % (
                                 2 * mates, mates, 97 * ((max_len + 63) // 64 * 64) + 1),
-                            "per_rank": per_rank}
+                            "per_rank": per_rank, "parity_check": parity}
             # like for like: efficiency(N) = value / (N * n1_reference.value)
             out["n1_reference"] = dict(n1_line, what="the same per-GPU workload (both mates, no exchange) on rank 0 alone, "
                                        "before the process group formed; scaling efficiency = value / (n_gpus * this value)")

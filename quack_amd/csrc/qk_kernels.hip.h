@@ -988,9 +988,17 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         // a fold point of the first-hit ring (kFhRing): every wave empties its queue, the workgroup meets, and the
         // entries of the reads before this step go to the kmer_count row.  (The reads of THIS group write other slots
         // — a group is at most half the ring —, and the next group starts behind the next barrier.)
+#if defined(QK_ABL) && (QK_ABL & 128)   /* experiment: fold points without the forced check of the queues (wrong counts) */
+        __syncthreads();
+        fold_first_hits(it_step);
+#elif defined(QK_ABL) && (QK_ABL & 256)   /* experiment: the forced checks without barrier and fold */
+        if (cand_n) drain_candidates();
+#elif defined(QK_ABL) && (QK_ABL & 512)   /* experiment: no fold points at all */
+#else
         if (cand_n) drain_candidates();
         __syncthreads();
         fold_first_hits(it_step);
+#endif
       } else if (ADAPT && MODE == 0 && !W16 && cand_n > kCandCap - 64u) {   // (W16: when a step's entries would not fit, see the push)
         drain_candidates();
       }

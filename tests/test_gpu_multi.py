@@ -116,6 +116,10 @@ def test_bench_under_the_drivers_launcher(tmp_path):
     share = line["also"]["cfg3_share"]
     assert "300 bp" in share["workload"] and share["n1_reference"]["value"] > 0 and len(share["per_rank"]) == 2
     assert "ONE all-reduce" in line["ranks"]["exchange"]
+    # round 4: the first thing a multi-rank run does is a correctness run — every rank its own reads (another longest read per
+    # rank), one exchange, the result against the oracle over the union
+    pc = line["ranks"]["parity_check"]
+    assert pc["ok"] is True and pc["reads"] == 3000 + 3400 + 2001 + 2002 and pc["max_length"] == 157 and pc["kmer_hits"] > 500
 
 
 def test_bench_fails_when_a_rank_fails():
