@@ -26,13 +26,15 @@ host: $(LIB_HIP)
 oracle:
 	$(MAKE) -C oracle
 
-tools: tools/kbench tools/gen_fastq
+tools: tools/kbench tools/gen_fastq tools/inflate_bench
+tools/inflate_bench: tools/inflate_bench.c $(HOST)/inflate_fast.c $(HOST)/inflate_body.inc $(HOST)/inflate_fast.h $(HOST)/crc32_fold.c
+	$(CC) -O3 -o $@ tools/inflate_bench.c $(HOST)/inflate_fast.c $(HOST)/crc32_fold.c -I$(HOST) -lz
 tools/gen_fastq: tools/gen_fastq.c
 	$(CC) -O2 -o $@ $< -lz
 tools/kbench: tools/kbench.cpp $(CSRC)/qk_shim.hip $(KERNEL_HDRS) include/quack_hip.h
 	$(HIPCC) $(HIPFLAGS) -DQK_ABLATION -o $@ tools/kbench.cpp $(CSRC)/qk_shim.hip -ldl
 
 clean:
-	rm -f $(LIB_HIP) tools/kbench tools/gen_fastq
+	rm -f $(LIB_HIP) tools/kbench tools/gen_fastq tools/inflate_bench
 	-$(MAKE) -C $(HOST) clean
 	-$(MAKE) -C oracle clean

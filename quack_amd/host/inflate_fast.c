@@ -25,6 +25,7 @@
 
 #define LITLEN_BITS 11
 #define DIST_BITS 8
+#define MULTI_BITS 12   /* index width of the literal-run table (qkh_inflate::multi) */
 #define MAX_CODE_LEN 15
 
 /* table entry: bits 0-4 code length to consume, 5-7 kind, 8-12 extra bits
@@ -249,6 +250,7 @@ int qkh_read_block_header(qkh_inflate *z) {
     }
     z->litlen = z->fixed_litlen;
     z->dist = z->fixed_dist;
+    z->multi = NULL;
     z->state = QKH_Z_CODES;
     return 0;
   }
@@ -288,6 +290,8 @@ int qkh_read_block_header(qkh_inflate *z) {
     if (build_table(z->dyn_dist, QKH_DIST_TABLE, DIST_BITS, lens + hlit, hdist, dist_entry)) return -1;
     z->litlen = z->dyn_litlen;
     z->dist = z->dyn_dist;
+    z->multi = NULL;
+    z->dyn_multi_ready = 0;
     z->state = QKH_Z_CODES;
     return 0;
   }
@@ -350,6 +354,67 @@ int64_t qkh_inflate_find_block(const uint8_t *data, size_t len, uint64_t from_bi
   return -1;
 }
 
+/* the literal-run table of the current literal/length code (qkh_inflate::multi): for every literal code, then every pair and
+ * triple of them that fits MULTI_BITS bits, one strided fill — an index belongs to the longest run it starts with, so the
+ * shorter runs are written first and overwritten (a lookup chain per index took 17 % of a FASTQ's decode time: blocks are
+ * ~30 KB) */
+static void build_multi(uint32_t *multi, const uint32_t *lt) {
+  struct lit_code { uint16_t code; uint8_t len, val; } c[256];
+  int n = 0;
+  memset(multi, 0, sizeof(uint32_t) << MULTI_BITS);
+  for (uint32_t idx = 0; idx < (1u << LITLEN_BITS); idx++) {
+    const uint32_t e = lt[idx];
+    if (E_KIND(e) == K_LIT && E_LEN(e) != 0 && idx < (1u << E_LEN(e)) && n < 256) {
+      c[n].code = (uint16_t)idx;     /* (the entry of a code is replicated at idx + k * 2^len: the lowest one names it) */
+      c[n].len = (uint8_t)E_LEN(e);
+      c[n].val = (uint8_t)E_VAL(e);
+      n++;
+    }
+  }
+  {   /* by code length (counting sort: lengths 1..11): the loops below stop at the first code that does not fit */
+    int at[LITLEN_BITS + 2] = {0};
+    struct lit_code t[256];
+    for (int i = 0; i < n; i++) at[c[i].len + 1]++;
+    for (int l = 1; l <= LITLEN_BITS + 1; l++) at[l] += at[l - 1];
+    for (int i = 0; i < n; i++) t[at[c[i].len]++] = c[i];
+    memcpy(c, t, (size_t)n * sizeof c[0]);
+  }
+#define FILL(bits, used, entry)                                                         \
+  for (uint32_t i_ = (bits); i_ < (1u << MULTI_BITS); i_ += 1u << (used)) multi[i_] = (entry)
+  for (int a = 0; a < n; a++) {
+    const uint32_t u1 = c[a].len, b1 = c[a].code, v1 = c[a].val;
+    FILL(b1, u1, u1 | (1u << 6) | (v1 << 8));
+    for (int b = 0; b < n; b++) {
+      const uint32_t u2 = u1 + c[b].len;
+      if (u2 > MULTI_BITS) break;
+      const uint32_t b2 = b1 | ((uint32_t)c[b].code << u1), v2 = v1 | ((uint32_t)c[b].val << 8);
+      FILL(b2, u2, u2 | (2u << 6) | (v2 << 8));
+      if (u2 + 1 > MULTI_BITS) continue;
+      for (int d = 0; d < n; d++) {
+        const uint32_t u3 = u2 + c[d].len;
+        if (u3 > MULTI_BITS) break;
+        FILL(b2 | ((uint32_t)c[d].code << u2), u3, u3 | (3u << 6) | ((v2 | ((uint32_t)c[d].val << 16)) << 8));
+      }
+    }
+  }
+#undef FILL
+}
+static void ensure_multi(qkh_inflate *z) {
+  if (z->litlen == z->fixed_litlen) {
+    if (!z->fixed_multi_ready) {
+      build_multi(z->fixed_multi, z->fixed_litlen);
+      z->fixed_multi_ready = 1;
+    }
+    z->multi = z->fixed_multi;
+  } else {
+    if (!z->dyn_multi_ready) {
+      build_multi(z->dyn_multi, z->dyn_litlen);
+      z->dyn_multi_ready = 1;
+    }
+    z->multi = z->dyn_multi;
+  }
+}
+
 uint64_t qkh_inflate_bitpos(const qkh_inflate *z) {
   return (uint64_t)(z->in - z->base) * 8u - (uint64_t)z->bitcnt;
 }
@@ -376,6 +441,8 @@ void qkh_inflate_clone(qkh_inflate *dst, const qkh_inflate *src) {
   else if (src->litlen == src->dyn_litlen) dst->litlen = dst->dyn_litlen;
   if (src->dist == src->fixed_dist) dst->dist = dst->fixed_dist;
   else if (src->dist == src->dyn_dist) dst->dist = dst->dyn_dist;
+  if (src->multi == src->fixed_multi) dst->multi = dst->fixed_multi;
+  else if (src->multi == src->dyn_multi) dst->multi = dst->dyn_multi;
 }
 
 /* ------------------------------------------------------------ member ends */

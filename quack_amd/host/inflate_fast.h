@@ -44,6 +44,13 @@ typedef struct {
   const uint32_t *litlen, *dist;
   uint32_t fixed_litlen[QKH_LITLEN_TABLE], fixed_dist[QKH_DIST_TABLE];
   uint32_t dyn_litlen[QKH_LITLEN_TABLE], dyn_dist[QKH_DIST_TABLE];
+  /* literal runs (round 4): what the next 12 bits hold when they START with literals — up to three of them per lookup
+   * (FASTQ is nearly all literals: bases take 2-3 bits, scores 5-6).  bits 0-5 the bits to consume, 6-7 the count
+   * (0: no literal there, take the ordinary table), 8-31 the literals.  Built from `litlen` when a block's first symbols
+   * are decoded (not when its header is parsed: the search for block starts parses many headers it never decodes). */
+  const uint32_t *multi;
+  int fixed_multi_ready, dyn_multi_ready;
+  uint32_t fixed_multi[4096], dyn_multi[4096];
 } qkh_inflate;
 
 /* The member ends of one delivered chunk of output (a ring block, a pinflate slice) and the
