@@ -85,6 +85,22 @@ def main():
             "lds_bank_conflict_share": (sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]) if sq.get("SQ_LDS_IDX_ACTIVE") else None,
             "wait_inst_any_over_wave_cycles": (sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_WAIT_INST_ANY") else None,
         }
+    # the whole step on the GPU's own clock: the period between the ENDS of consecutive histogram-kernel dispatches in the kernel
+    # trace (every kernel of a step lies between them, whichever stream it ran on), and what else ran in a step
+    step = {}
+    for f in newest(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))):
+        disp = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))), key=lambda x: x[1])
+        ends = [e for s_, e, n in disp if kern in n]
+        if len(ends) > 60:
+            per = sorted(b_ - a_ for a_, b_ in zip(ends[50:-1], ends[51:]))      # (past the warm-up)
+            own = sorted(e - s_ for s_, e, n in disp if kern in n)[len(ends) // 10:]
+            others = collections.defaultdict(list)
+            for s_, e, n in disp:
+                if kern not in n and "qk::" in n:     # (the product's own kernels; torch's batch-making kernels precede the loop)
+                    others[n.split("(")[0][-60:]].append(e - s_)
+            step = {"dispatches": len(ends), "period_ns_median": per[len(per) // 2], "period_ns_mean": sum(per) / len(per),
+                    "hist_kernel_ns_median": own[len(own) // 2],
+                    "other_kernels_per_step": {n: {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": min(v)} for n, v in others.items()}}
     calib, _ = counters(os.path.join(src, "pmc_calib"), kern)
     fetch_b = pmc.get("FETCH_SIZE", 0) * 1024
     write_b = pmc.get("WRITE_SIZE", 0) * 1024
@@ -94,7 +110,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes, "pmc_per_launch": pmc, "pmc_samples": cnt,
             "hbm_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / alg_bytes,
             "achieved_GBs_from_trace": alg_bytes / float(k["AverageNs"]),
-            "sq_per_launch": sq, "sq_derived": sq_derived}
+            "sq_per_launch": sq, "sq_derived": sq_derived, "step_from_kernel_trace": step}
     if calib:
         info["calibration_loads_only_FETCH_SIZE_KB"] = calib.get("FETCH_SIZE")
         info["calibration_factor_for_8B_per_lane"] = alg_bytes / (calib["FETCH_SIZE"] * 1024)
@@ -127,6 +143,13 @@ def main():
                        d["vmem_rd_insts_per_wave_chunk"], 100 * (d["valu_busy_share_of_simd_cycles"] or 0), d["kernel_cycles"],
                        d["clock_GHz_implied"] or 0, 100 * (d["lds_bank_conflict_share"] or 0),
                        100 * (d["wait_inst_any_over_wave_cycles"] or 0)))
+        if step:
+            f.write("\nWhole step from the kernel trace's begin / end timestamps: the period between the ends of consecutive histogram-kernel dispatches is "
+                    "%.1f us (median; mean %.1f) for a kernel of %.1f us (median) — algorithmic bytes / period = %.0f GB/s = %.3f of 8 TB/s for the whole step.  "
+                    "Other kernels of a step (their trace durations are NOT additive: on the side stream they wait behind the histogram kernel): %s\n"
+                    % (step["period_ns_median"] / 1e3, step["period_ns_mean"] / 1e3, step["hist_kernel_ns_median"] / 1e3, alg_bytes / step["period_ns_median"],
+                       alg_bytes / step["period_ns_median"] / 8000.0,
+                       "; ".join("%s x%d avg %.1f us (min %.1f)" % (n, v["calls"], v["avg_ns"] / 1e3, v["min_ns"] / 1e3) for n, v in step["other_kernels_per_step"].items()) or "none"))
         if calib:
             f.write("\nCalibration (loads-only build, every byte read once, same 8 B/lane pattern): FETCH_SIZE %.0f KB "
                     "=> factor %.3f (the guide's 2.0 is for 16 B/lane)\n"
