@@ -429,7 +429,11 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     }
   };
 
+#if defined(QK_ABL) && (QK_ABL & 1024)   /* experiment: what a launch costs without loading the adapter tables */
+  if (false) {
+#else
   if (ADAPT) {
+#endif
     for (uint32_t i = tid; i < kFusedFilterWords; i += T) lds_filter[i] = p.kmer_filter[kFusedFilterWords + i];
     if (p.bucket_log2)
       for (uint32_t i = tid; i < (1u << p.bucket_log2); i += T) lds_buckets[i] = p.kmer_buckets[i];
@@ -541,12 +545,18 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   };
 
   auto zero_lds = [&]() {
+#if defined(QK_ABL) && (QK_ABL & 2048)   /* experiment: ... without clearing the LDS image */
+    return;
+#endif
     for (uint32_t i = tid; i < hist_words + (ADAPT ? 6u : 5u) * TP + 1u; i += T) lds[i] = 0;
   };
 
   // ---- flush: LDS -> planar u64 table; zero counters are skipped.  One wave
   // per quality row, lanes along positions (contiguous 512-B atomics).
   auto flush = [&](uint32_t tile) {
+#if defined(QK_ABL) && (QK_ABL & 4096)   /* experiment: ... without the flush */
+    return;
+#endif
     const uint32_t P0 = tile * p.tile_pos;
     if (!FAST_FIXED && tile == 0 && n_gt10) {
       lds_add(lds_misc, 0, n_gt10);

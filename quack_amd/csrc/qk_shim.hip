@@ -11,7 +11,6 @@
 #include <dlfcn.h>
 #include <unistd.h>
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -488,7 +487,6 @@ uint32_t padded_stride_for(const qk_accum *a, uint32_t read_len) {
   return (read_len + 3u) & ~3u;
 }
 
-thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;   // set by the submit path for a timed launch, taken by launch_hist_tu
 
 template <int T, int U, int PD>
 int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, bool aligned, bool strided, bool w16, dim3 grid,
@@ -582,14 +580,7 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
   }
   static bool first_launch = true;   // (QUACK_VERBOSE: the first launch of the process loads the code object)
   Lap lap;
-  if (t_ev0 && t_ev1) {
-    // timed launch: the dispatch packet itself carries the two events (its own start and end timestamps) — no marker
-    // packets around the kernel, which cost ~10 us of stream time per launch and sat in what bench.py reports as a step
-    hipExtLaunchKernelGGL(k, grid, dim3(T), (uint32_t)lds, st, t_ev0, t_ev1, 0u, hp);
-    t_ev0 = t_ev1 = nullptr;
-  } else {
-    hipLaunchKernelGGL(k, grid, dim3(T), lds, st, hp);
-  }
+  hipLaunchKernelGGL(k, grid, dim3(T), lds, st, hp);
   QK_HIP(hipGetLastError());
   if (first_launch && lap.on) {
     first_launch = false;
@@ -884,16 +875,13 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
 
   // one tile: the histogram kernel resets first_hit[] and takes the kmer_count of its own reads
   hp.count_in_kernel = pl.fused_adapters && pl.n_tiles == 1 && !getenv("QUACK_HIP_SEPARATE_COUNT");
-  // (opt-in: one full test run out of three stopped making progress the evening this went in — never reproduced, never
-  // traced to it either, so the markers stay the default)
-  const bool ext_events = timed && getenv("QUACK_HIP_EXT_EVENTS") != nullptr;
-  if (timed && !ext_events) QK_HIP(hipEventRecord(tl.t0, st));
+  // (Round 3 had an opt-in that handed the two events to the dispatch packet itself — hipExtLaunchKernelGGL, 0.5 % of a step —
+  // and one of three full test runs with it stopped making progress; never root-caused, so round 4 removed it.)
+  if (timed) QK_HIP(hipEventRecord(tl.t0, st));
   if (pl.fused_adapters && !hp.count_in_kernel) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
-  if (ext_events) t_ev0 = tl.t0, t_ev1 = tl.t1;
   rc = launch_hist(a, hp, pl, d_off == nullptr, g_ablation_mode, pl.fused_adapters, st, strided);
-  t_ev0 = t_ev1 = nullptr;
   if (rc) return rc;
-  if (timed && !ext_events) QK_HIP(hipEventRecord(tl.t1, st));
+  if (timed) QK_HIP(hipEventRecord(tl.t1, st));
   if (a->adapters && !hp.count_in_kernel) {
     // fused: the histogram pass already left first_hit[]; otherwise scan now
     rc = pl.fused_adapters ? qk::launch_adapter_count(hp, a->n_cu, st) : qk::launch_adapter_scan(hp, a->n_cu, st);

@@ -119,6 +119,7 @@ def test_padded_fixed_length_every_length(adapters, monkeypatch):
     with a padded layout (qk_accum_submit_device_strided, lengths NULL; garbage in the pad bytes), and the packed
     device API (the 12-byte-window kernels): 3 x the oracle's table."""
     import torch
+    overridden = [e for e in os.environ if e.startswith("QUACK_HIP_")]      # (tools/stress_gpu.sh runs this file under overrides)
     if not adapters:
         monkeypatch.setenv("QUACK_HIP_PAD_ALWAYS", "1")   # (the feeds pad by themselves only with the adapter scan)
     ads = synth.synthetic_adapters()
@@ -141,7 +142,8 @@ def test_padded_fixed_length_every_length(adapters, monkeypatch):
         stride = (L + 3) & ~3
         s2, q2 = padded_layout(seq, qual, n, L, stride)
         with quack_amd.Accumulator(0, bits) as acc:
-            assert acc.padded_stride(L) == (stride if L % 4 and L >= 16 or (L % 4 and not adapters) else 0)
+            if not overridden:
+                assert acc.padded_stride(L) == (stride if L % 4 and L >= 16 or (L % 4 and not adapters) else 0)
             acc.submit_fixed(seq, qual, L)
             d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
             acc.submit_device_padded(d_s, d_q, n, L, stride)
@@ -235,8 +237,7 @@ def test_padded_batches_through_the_pinned_slots_and_under_overrides(monkeypatch
             seq, qual = synth.fixed(n, L, seed=L + 1)
             seq = synth.splice_adapters(seq, L, ads, seed=L + 2, fraction=0.5)
             want = ob.accumulate_batch(seq, qual, read_len=L, kmers=k)
-            stride = acc.padded_stride(L)
-            assert stride == (L + 3) & ~3
+            stride = acc.padded_stride(L) or (L + 3) & ~3      # (0 under a tuning override: the explicit form still works)
             s2, q2 = padded_layout(seq, qual, n, L, stride)
             hs, hq, _ = acc.acquire()
             hs[:n * stride] = s2

@@ -65,3 +65,33 @@ def test_cache_line_plans():
     assert not p["aligned"] and p["n_tiles"] == 1
     with pytest.raises(RuntimeError):
         plan(10, 0xFFFFFFF0, ragged=True)                                # a read that no slice can address
+
+
+def test_rows_of_several_reads():
+    """round 4 (choose_group + the plan of a row, qk_debug_group): fixed-length reads with the adapter scan are taken as rows
+    of several reads where that fills the 16-position lanes better; whatever is chosen, a row fits one tile beside the adapter
+    tables, runs 16 positions per lane, and a step's reads fit half the smallest first-hit ring"""
+    L.qk_debug_group.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
+
+    def group(n, read_len, stride, blog=9):
+        out = (ctypes.c_uint64 * 8)()
+        assert L.qk_debug_group(n, read_len, stride, blog, out) == 0, L.qk_last_error()
+        return dict(zip("group row tile_pos rw unroll w16 bucket_log2 lds".split(), out))
+
+    want = {36: 4, 50: 4, 76: 4, 100: 3, 125: 1, 150: 2, 151: 2, 200: 1, 250: 1, 300: 1}
+    for read_len, g in want.items():
+        p = group(10_000_000, read_len, (read_len + 3) & ~3)
+        assert p["group"] == g, (read_len, p)
+    for read_len in list(range(11, 330)) + [400, 448, 500]:
+        for blog in (0, 6, 9, 10):
+            stride = (read_len + 3) & ~3
+            p = group(1_000_000, read_len, stride, blog)
+            assert p["lds"] <= 160 * 1024, (read_len, blog, p)
+            assert p["row"] == (p["group"] - 1) * stride + read_len
+            if p["group"] > 1:
+                assert p["w16"] == 1 and p["tile_pos"] >= p["row"] and p["tile_pos"] % 16 == 0 and p["tile_pos"] <= 320, (read_len, blog, p)
+                assert p["rw"] * p["unroll"] * p["group"] <= 1024, (read_len, blog, p)
+                assert p["bucket_log2"] == blog or blog == 0, (read_len, blog, p)      # never at the price of the exact LDS table
+                lanes1 = -(-read_len // 16) * 16 / read_len
+                lanesg = p["tile_pos"] / (p["group"] * read_len)
+                assert lanesg < lanes1 * 0.985, (read_len, p)                          # ... and only where it pays

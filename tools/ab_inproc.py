@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dummy-mb", type=int, default=0, help="device memory allocated (and kept) before the first accumulator")
     ap.add_argument("--splice", type=float, default=None, help="share of the reads that carry a spliced adapter (adapter workloads)")
     ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--reads", type=int, default=None)
     ap.add_argument("settings", nargs="*")
     a = ap.parse_args()
     settings = [("" if s == "-" else s) for s in a.settings] or ["", ""]
@@ -36,6 +37,8 @@ def main():
     w = dict(bench.WORKLOADS[a.workload])
     if a.splice is not None:
         w["splice"] = a.splice
+    if a.reads:
+        w["n"] = a.reads
     if a.read_len:
         w["L"] = a.read_len
         if w.get("pad"):
