@@ -81,9 +81,12 @@ WORKLOADS = {
     "cfg4": dict(n=6_250_000, L=150, ragged=None, adapters=False, paired=True,
                  label="paired 2x50M 150 bp sharded over 8 GPUs: per-GPU share 2 x 6.25M reads (configs[3])"),
     # trimmed Illumina: 150 bp reads, most of them full length, the rest cut back to 120..149
-    "trimmed": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7, stride=152,
+    "trimmed": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7, stride=152, neutral=True,
                     label="10M-read synthetic trimmed 150 bp FASTQ (70% full length, rest 120-149), fixed stride 152 + "
-                          "per-read lengths as the host feed lays such reads out"),
+                          "per-read lengths, 0xFF behind every read, as the host feed lays such reads out"),
+    "trimmedmasked": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7, stride=152,
+                          label="10M-read synthetic trimmed 150 bp FASTQ (70% full length, rest 120-149), fixed stride 152 + "
+                                "per-read lengths, arbitrary bytes behind the reads (the kernel masks the tails)"),
     "trimmedpacked": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7,
                           label="10M-read synthetic trimmed 150 bp FASTQ (70% full length, rest 120-149), packed ragged"),
 }
@@ -198,6 +201,15 @@ def make_batch(torch, np, w, seed, device, quality="uniform", q_hi_override=None
             qual[a:b] = levels[idx]
         else:
             qual[a:b] = (33 + torch.randint(q_lo, q_hi + 1, (b - a,), generator=g, device=device)).to(torch.uint8)
+    if w["ragged"] and w.get("stride") and w.get("neutral"):
+        # the host feed writes 0xFF behind every read of a strided batch (QK_BATCH_NEUTRAL_PADS)
+        st = w["stride"]
+        col = torch.arange(st, device=device)
+        for a in range(0, w["n"], 1 << 20):
+            e = min(w["n"], a + (1 << 20))
+            pad = col[None, :] >= d_len[a:e, None]
+            seq[a * st:e * st].view(e - a, st)[pad] = 255
+            qual[a * st:e * st].view(e - a, st)[pad] = 255
     spliced = 0
     if ads is not None and w.get("splice") and d_off is None:
         # a quarter of the reads get one adapter at a uniform offset, truncated at the
@@ -217,7 +229,7 @@ def make_batch(torch, np, w, seed, device, quality="uniform", q_hi_override=None
         spliced = int(len(pick))
     torch.cuda.synchronize(device)   # (made on torch's stream; the accumulators launch on their own streams, which wait for nobody)
     return dict(seq=seq, qual=qual, d_off=d_off, d_len=d_len, total=total, max_len=max_len, extent=extent,
-                n=w["n"], spliced=spliced, stride=w.get("stride") if w["ragged"] else None,
+                n=w["n"], spliced=spliced, stride=w.get("stride") if w["ragged"] else None, neutral=bool(w.get("neutral")),
                 pad=w.get("pad") if not w["ragged"] else None)
 
 
@@ -363,7 +375,8 @@ class Job:
 
     def submit(self, acc, b, stream):
         if b.get("stride"):
-            acc.submit_device_strided(b["seq"], b["qual"], b["d_len"], b["n"], b["stride"], b["max_len"], stream=stream)
+            acc.submit_device_strided(b["seq"], b["qual"], b["d_len"], b["n"], b["stride"], b["max_len"], stream=stream,
+                                      neutral_pads=b.get("neutral", False))
         elif b.get("pad"):
             acc.submit_device_padded(b["seq"], b["qual"], b["n"], b["max_len"], b["pad"], stream=stream)
         elif b["d_len"] is not None:

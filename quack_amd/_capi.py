@@ -19,6 +19,7 @@ QK_ROW_KMER = 96
 QK_KMER_TABLE_WORDS = (1 << 20) // 32
 QK_TAIL_SLACK = 16
 QK_BATCH_ALIGNED128 = 1
+QK_BATCH_NEUTRAL_PADS = 2
 QK_ENODEV = -2
 
 
@@ -74,6 +75,9 @@ def bind_hip(L):
     L.qk_accum_submit_device_strided.argtypes = [c_vp, c_vp, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint32,
                                                  ctypes.c_uint32, c_vp]
     L.qk_accum_commit_strided.argtypes = [c_vp, ctypes.c_uint64, ctypes.c_uint32]
+    L.qk_accum_submit_device_strided_flags.argtypes = [c_vp, c_vp, c_vp, c_vp, ctypes.c_uint64, ctypes.c_uint32,
+                                                       ctypes.c_uint32, ctypes.c_uint32, c_vp]
+    L.qk_accum_commit_strided_flags.argtypes = [c_vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
     L.qk_accum_padded_stride.argtypes = [c_vp, ctypes.c_uint32, c_u32p]
     L.qk_accum_commit_padded.argtypes = [c_vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32]
     L.qk_accum_submit_strided.argtypes = [c_vp, c_vp, c_vp, c_vp, ctypes.c_uint32, ctypes.c_uint64]

@@ -6,7 +6,7 @@ import tempfile
 import numpy as np
 
 from . import _capi
-from ._capi import QK_BATCH_ALIGNED128, QK_KMER_TABLE_WORDS, QK_N_ROWS, QK_TAIL_SLACK
+from ._capi import QK_BATCH_ALIGNED128, QK_BATCH_NEUTRAL_PADS, QK_KMER_TABLE_WORDS, QK_N_ROWS, QK_TAIL_SLACK
 
 
 class HipUnavailable(RuntimeError):
@@ -203,12 +203,13 @@ class Accumulator:
             self._h, d_seq.data_ptr(), d_qual.data_ptr(), d_starts.data_ptr(), d_lengths.data_ptr(),
             n_reads, extent_bytes, max_len, QK_BATCH_ALIGNED128 if aligned else 0, stream))
 
-    def submit_device_strided(self, d_seq, d_qual, d_lengths, n_reads, stride, max_len, stream=None):
+    def submit_device_strided(self, d_seq, d_qual, d_lengths, n_reads, stride, max_len, stream=None, neutral_pads=False):
         """read r at [r*stride, r*stride + lengths[r]); lengths: int32/uint32[n] device tensor; stride % 4 == 0;
-        see qk_accum_submit_device_strided"""
-        _check(self._L.qk_accum_submit_device_strided(
+        neutral_pads: the caller promises 0xFF behind every read's last base (QK_BATCH_NEUTRAL_PADS: the kernel without tail
+        masks); see qk_accum_submit_device_strided"""
+        _check(self._L.qk_accum_submit_device_strided_flags(
             self._h, d_seq.data_ptr(), d_qual.data_ptr(), d_lengths.data_ptr() if d_lengths is not None else None,
-            n_reads, stride, max_len, stream))
+            n_reads, stride, max_len, QK_BATCH_NEUTRAL_PADS if neutral_pads else 0, stream))
 
     def submit_device_padded(self, d_seq, d_qual, n_reads, read_len, stride, stream=None):
         """fixed-length reads of read_len bases, read r at r*stride (stride % 4 == 0, >= read_len): the layout the host

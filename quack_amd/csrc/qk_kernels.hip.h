@@ -377,8 +377,9 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 // (the long-read build — ragged, W16, no adapter scan — is held to 120 VGPRs: four of its waves then leave 32 registers of
 // a SIMD free, which is what the waves of the NEXT batch's reach pre-pass (12-16 VGPRs, 2 KiB of LDS) need to run beside it
 // on the side stream instead of waiting for a workgroup to retire)
-template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false>
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false, bool NP = false>
 __device__ __forceinline__ void hist_body(const HistParams &p) {
+  static_assert(!NP || SV, "neutral pads are a property of strided batches");
   static_assert(!SV || (FIXED && AL), "strided batches are a variant of the dword-aligned fixed-length path");
   static_assert(!W16 || (AL && !SV && MODE == 0), "16 positions per lane: dword-aligned batches only");
   constexpr bool STAGED = !FIXED;   // ragged batches: the read list is staged in LDS pass by pass
@@ -510,7 +511,14 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   // go one step further: the tail is a per-lane constant (fixed_mask), lanes past
   // the end of the slice sit out under the exec mask and count their own
   // events (steps_v), and no per-event valid counter is needed at all.
-  constexpr bool FAST_FIXED = FIXED && !SV;
+  // NP (round 4; strided batches whose pad bytes — behind a read's last base, up to the stride — are 0xFF, as the host feed
+  // writes them): a pad byte counts into quality row 127, which the flush discards, and matches none of T / C / G, so the
+  // strided kernel needs no tail masks either; what a position's `valid` count is — content[A] = valid - T - C - G — comes
+  // from the lengths the step loop counts anyway (reads longer than the position), at flush time.  The masks were 30 of the
+  // strided kernel's 94 VALU instructions per chunk; the kernel is mostly bound by how its three load streams arrive, so the
+  // gain is 2.3 % (10M trimmed 150 bp reads 0.5300 -> 0.5178 ms in one process, 0.696 -> 0.712 of peak).
+  constexpr bool FAST_FIXED = FIXED && (!SV || NP);   // no tail masks
+  constexpr bool UNIFORM = FIXED && !SV;              // every read one length: lengths in closed form
   uint32_t events = 0, steps_v = 0;
   uint32_t fixed_mask = 0;   // FIXED: which of the lane's 8K positions are bases of a read (the same for every row): bit i = position cpos + i
 
@@ -558,13 +566,14 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     return;
 #endif
     const uint32_t P0 = tile * p.tile_pos;
-    if (!FAST_FIXED && tile == 0 && n_gt10) {
+    if (!UNIFORM && tile == 0 && n_gt10) {
       lds_add(lds_misc, 0, n_gt10);
       n_gt10 = 0;
     }
     __syncthreads();
     // fixed-length batches count unmasked: columns at and behind read_len hold the next read's bytes
-    const uint32_t pos_limit = (FIXED && p.read_len < p.table_len) ? p.read_len : p.table_len;
+    uint32_t pos_limit = (FIXED && p.read_len < p.table_len) ? p.read_len : p.table_len;
+    if (NP && p.len_limit < pos_limit) pos_limit = p.len_limit;   // (columns behind the longest read hold pads and the next read's bytes)
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     // grouped rows: position pp of the reads lives in the columns pp, pp + gstride, ... (one per read of a row); summed here
     const uint32_t span = (GROUPS && GRP > 1u) ? p.read_len : TP;
@@ -596,6 +605,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         g += lds_base[3u * TP + col];
       }
       const uint32_t pos = P0 + pp;
+      if (NP) {   // reads (of this workgroup, since its last flush) longer than the position: from the lengths counted in the loop
+        v = 0;
+        for (uint32_t j = pp; j < TP; ++j) v += lds_len[j];
+      }
       if (v == 0 || pos >= pos_limit) continue;
       const uint32_t a = v - t - c - g;                     // content[] order: A,T,C,G (quack.c:150)
       if (p.table32) {
@@ -612,7 +625,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         if (g) atomicAdd(row0 + 3u * TL, (unsigned long long)g);
       }
     }
-    if (!FAST_FIXED && !p.lengths_done) {
+    if (!UNIFORM && !p.lengths_done) {
       // reads that END in this tile (staged once per tile they reach, so each read counts exactly once)
       for (uint32_t pp = tid; pp < TP; pp += T) {
         const uint32_t c = lds_len[pp];
@@ -628,7 +641,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       }
     }
     if (tile == 0) {
-      if (FAST_FIXED) {
+      if (UNIFORM) {
         if (tid == 0 && fixed_reads != 0) {
           const unsigned long long n = (unsigned long long)fixed_reads * GRP;   // (fixed_reads counts rows)
           if (p.read_len != 0)
@@ -850,6 +863,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           n_raw = n_raw > 8u * K ? 8u * K : n_raw;
           nv[u] = lane_on ? n_raw : 0u;
           // strided: the read's own length, in flight together with its bytes (consume turns it into n)
+          // (NP: only the lane that counts the length needs it; loading it in that lane alone was measured: 0.5082 / 0.5091 ms)
           if (SV) nv[u] = in_list ? p.lengths[(size_t)r_begin + rel] : 0u;
           off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
           sk[u] = AL ? 0u : (off & 3u);
@@ -1021,6 +1035,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         if (SV) {   // nv[u] is the length of the read
           nl = (lane_on && nv[u] > cpos) ? nv[u] - cpos : 0u;
           nl = nl > 8u ? 8u : nl;
+          if (NP) nl = (lane_on && nv[u] != 0u) ? 8u : 0u;   // (every byte of an existing read row counts: pads are neutral)
           // length_count (quack.c:219) and the kmers==NULL count (quack.c:215) by the lane that owns the read's first
           // chunk: the length is in its register anyway.  (Late round 3; round 2 counted behind the step loop, a pass
           // of its own over lengths[], and gained nothing over the separate kernel: 24 us per 10M reads.)
@@ -1491,9 +1506,11 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   if (cur_tile != 0xFFFFFFFFu) flush(cur_tile);
 }
 
-template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false>
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false, bool NP = false>
+// (strided builds without the adapter scan are held to 64 VGPRs for two workgroups per CU — also the one without tail masks, NP:
+// measured with one workgroup 0.5975 ms per 10M trimmed 150 bp reads, with two 0.5178; the masked build 0.5300)
 __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
-  hist_body<T, U, FIXED, MODE, ADAPT, PD, AL, SV, W16>(p);
+  hist_body<T, U, FIXED, MODE, ADAPT, PD, AL, SV, W16, NP>(p);
 }
 
 // (A build of the long-read variant held to 120 VGPRs — four of its waves then leave 32 registers of a SIMD free, room for

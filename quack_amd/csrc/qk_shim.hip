@@ -249,6 +249,7 @@ struct Plan {
   bool fused_adapters, dynamic, aligned, sorted;
   bool w16;   // 16 positions per lane (qk::hist_kernel<..., W16>): dword-aligned batches under the planner's own geometry
   uint32_t fh_words;   // first-hit ring of the fused adapter path (fixed-length batches): the largest power of two the LDS has room for
+  bool neutral;        // strided batch whose pad bytes are 0xFF (QK_BATCH_NEUTRAL_PADS): the kernel variant without tail masks
 };
 constexpr unsigned kQueueRing = 8;       // queue sets that rotate (launches of one accumulator run in order)
 constexpr unsigned kQueueTiles = 1u << 17;  // counters per launch: reads of up to 64 Mbases (512-position tiles)
@@ -296,7 +297,7 @@ uint32_t choose_group(const qk_accum *a, uint64_t n_reads, uint32_t read_len, ui
 }
 
 int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, bool gapped, bool aligned, Plan *pl,
-              bool base_aligned4 = true, bool strided = false, uint32_t addr_stride = 0) {
+              bool base_aligned4 = true, bool strided = false, uint32_t addr_stride = 0, bool neutral_req = false) {
   const uint32_t T = (uint32_t)a->threads;
   // fixed-length reads: the distance between two reads — the read length, or (padded batches, round 4) the multiple of 4
   // above it: what decides whether every chunk starts on a dword is the stride, not the length
@@ -424,6 +425,9 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // threads per CU, and the LDS image must fit as many times
   uint32_t wgs = a->wgs_per_cu > 0 ? (uint32_t)a->wgs_per_cu
                                    : std::max<uint32_t>(1, std::min<uint32_t>(1024 / T, (uint32_t)(160 * 1024 / lds)));
+  // strided batches with neutral pads (0xFF behind every read): the variant without tail masks — one tile, lengths counted in
+  // the step loop (which is where a position's `valid` count comes from), the planner's own geometry
+  pl->neutral = neutral_req && strided && n_tiles == 1 && !tuned && T == 1024 && !getenv("QUACK_HIP_LENGTH_KERNEL") && !getenv("QUACK_HIP_NO_NEUTRAL");
   // strided batches without the adapter scan: the kernel is built for 64 VGPRs and runs two
   // workgroups per CU when the LDS holds two histograms (reads of up to ~190 bases)
   if (strided && !pl->fused_adapters && a->wgs_per_cu <= 0 && T == 1024) {
@@ -490,7 +494,7 @@ uint32_t padded_stride_for(const qk_accum *a, uint32_t read_len) {
 
 template <int T, int U, int PD>
 int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, bool aligned, bool strided, bool w16, dim3 grid,
-                   size_t lds, hipStream_t st) {
+                   size_t lds, hipStream_t st, bool neutral = false) {
   void (*k)(const qk::HistParams) = nullptr;
   if (w16) {
     // 16 positions per lane: built for the step shapes the planner (or QUACK_HIP_W16_U / _PD) asks for
@@ -508,10 +512,10 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
     // fixed stride + per-read lengths: built for the planner's own choice only
     if (fixed && aligned && mode == 0) {
       if constexpr (T == 1024 && PD == 2 && U == 1) {
-        if (!adapt) k = qk::hist_kernel<T, U, true, 0, false, PD, true, true>;
+        if (!adapt) k = neutral ? qk::hist_kernel<T, U, true, 0, false, PD, true, true, false, true> : qk::hist_kernel<T, U, true, 0, false, PD, true, true>;
       }
       if constexpr (T == 1024 && PD == 2 && U == 2) {
-        if (adapt) k = qk::hist_kernel<T, U, true, 0, true, PD, true, true>;
+        if (adapt) k = neutral ? qk::hist_kernel<T, U, true, 0, true, PD, true, true, false, true> : qk::hist_kernel<T, U, true, 0, true, PD, true, true>;
       }
     }
     if (!k) return fail(QK_EINVAL, "strided batches run with the planner's own launch geometry only (threads/unroll/pipe overrides are set)");
@@ -592,10 +596,11 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
 
 int launch_hist(qk_accum *a, const qk::HistParams &hp, const Plan &pl, bool fixed, int mode, bool adapt,
                 hipStream_t st, bool strided = false) {
+  const bool neutral = strided && pl.neutral;
   const size_t lds = qk::hist_lds_bytes(hp.ch, pl.replicas, adapt, hp.bucket_log2, !fixed, pl.stage_reads, pl.w16, pl.fh_words);
   dim3 grid((unsigned)pl.n_blocks);
 #define QK_TU(TT, UU, PP) \
-  if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, strided, pl.w16, grid, lds, st);
+  if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, strided, pl.w16, grid, lds, st, neutral);
   QK_TU(1024, 4, 1) QK_TU(1024, 2, 1) QK_TU(1024, 1, 1)
   QK_TU(1024, 4, 2) QK_TU(1024, 2, 2) QK_TU(1024, 1, 2)
   QK_TU(1024, 2, 3) QK_TU(1024, 2, 4) QK_TU(1024, 1, 4)
@@ -682,7 +687,8 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     }
   } else {
     rc = make_plan(a, n_reads, strided ? stride : max_len, d_off != nullptr, d_off && d_len,
-                   d_off && d_len && (flags & QK_BATCH_ALIGNED128), &pl, base4, strided, padded ? stride : 0u);
+                   d_off && d_len && (flags & QK_BATCH_ALIGNED128), &pl, base4, strided, padded ? stride : 0u,
+                   strided && (flags & QK_BATCH_NEUTRAL_PADS));
     if (rc) return rc;
   }
   if (strided) {
@@ -691,6 +697,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     // reads run as gapped batches — starts[i] = i * stride written by a small kernel, lengths[] as they are —
     // in chunks below the 2 GiB a gapped batch may span.  Same counters, the ragged kernels' speed.
     const bool native = pl.aligned && a->threads == 1024 && pl.pipe == 2 && pl.unroll == (pl.fused_adapters ? 2 : 1);
+    if (!native) pl.neutral = false;
     if (!native) {
       if (a->starts_scratch_reads < n_reads) {
         QK_HIP(hipDeviceSynchronize());
@@ -1539,7 +1546,14 @@ int qk_accum_submit_device_gapped(qk_accum *a, const void *d_seq, const void *d_
 
 int qk_accum_submit_device_strided(qk_accum *a, const void *d_seq, const void *d_qual, const void *d_lengths,
                                    uint64_t n_reads, uint32_t stride, uint32_t max_len, void *hip_stream) {
+  return qk_accum_submit_device_strided_flags(a, d_seq, d_qual, d_lengths, n_reads, stride, max_len, 0u, hip_stream);
+}
+
+int qk_accum_submit_device_strided_flags(qk_accum *a, const void *d_seq, const void *d_qual, const void *d_lengths,
+                                         uint64_t n_reads, uint32_t stride, uint32_t max_len, uint32_t flags, void *hip_stream) {
   if (!a || (n_reads && max_len && (!d_seq || !d_qual))) return fail(QK_EINVAL, "NULL argument");
+  if (flags & ~QK_BATCH_NEUTRAL_PADS) return fail(QK_EINVAL, "unknown flags 0x%x", flags);
+  if ((flags & QK_BATCH_NEUTRAL_PADS) && !d_lengths) return fail(QK_EINVAL, "QK_BATCH_NEUTRAL_PADS is a promise about a batch with lengths[]");
   if (stride == 0 || (stride & 3u) || max_len > stride) return fail(QK_EINVAL, "stride must be a multiple of 4 and >= max_len");
   // d_lengths == NULL: every read is max_len long — a fixed-length batch at a padded stride
   if ((((uintptr_t)d_seq | (uintptr_t)d_qual) & 3u) != 0) return fail(QK_EINVAL, "strided batches must start on a 4-byte boundary");
@@ -1560,7 +1574,7 @@ int qk_accum_submit_device_strided(qk_accum *a, const void *d_seq, const void *d
     d_hit = a->d_hit_scratch;
   }
   return enqueue_batch(a, (const uint8_t *)d_seq, (const uint8_t *)d_qual, nullptr, d_hit, n_reads,
-                       n_reads * (uint64_t)stride, max_len, st, (const uint32_t *)d_lengths, 0, stride);
+                       n_reads * (uint64_t)stride, max_len, st, (const uint32_t *)d_lengths, flags, stride);
 }
 
 int qk_accum_submit_strided(qk_accum *a, const uint8_t *seq, const uint8_t *qual, const uint32_t *lengths,
@@ -1583,7 +1597,14 @@ int qk_accum_submit_strided(qk_accum *a, const uint8_t *seq, const uint8_t *qual
     memcpy(hs, seq + i * stride, n * stride);
     memcpy(hq, qual + i * stride, n * stride);
     memcpy(hl, lengths + i, n * sizeof(uint32_t));
-    if ((rc = qk_accum_commit_strided(a, n, stride))) {
+    // the slot is ours: the bytes behind every read become 0xFF, and the batch runs the kernel without tail masks
+    const bool neutral = !getenv("QUACK_HIP_NO_NEUTRAL");
+    for (uint64_t r = 0; neutral && r < n; ++r)
+      if (hl[r] < stride) {
+        memset(hs + r * stride + hl[r], 0xFF, stride - hl[r]);
+        memset(hq + r * stride + hl[r], 0xFF, stride - hl[r]);
+      }
+    if ((rc = qk_accum_commit_strided_flags(a, n, stride, neutral ? QK_BATCH_NEUTRAL_PADS : 0u))) {
       a->held_slot = -1;
       return rc;
     }
@@ -1593,7 +1614,12 @@ int qk_accum_submit_strided(qk_accum *a, const uint8_t *seq, const uint8_t *qual
 }
 
 int qk_accum_commit_strided(qk_accum *a, uint64_t n_reads, uint32_t stride) {
+  return qk_accum_commit_strided_flags(a, n_reads, stride, 0u);
+}
+
+int qk_accum_commit_strided_flags(qk_accum *a, uint64_t n_reads, uint32_t stride, uint32_t flags) {
   if (!a) return fail(QK_EINVAL, "acc is NULL");
+  if (flags & ~QK_BATCH_NEUTRAL_PADS) return fail(QK_EINVAL, "unknown flags 0x%x", flags);
   if (a->held_slot < 0) return fail(QK_ESTATE, "no batch acquired");
   if (stride == 0 || (stride & 3u)) return fail(QK_EINVAL, "stride must be a multiple of 4");
   Slot &s = a->slot[a->held_slot];
@@ -1603,8 +1629,15 @@ int qk_accum_commit_strided(qk_accum *a, uint64_t n_reads, uint32_t stride) {
   if (rc) return rc;
   uint32_t max_len = 0;
   for (uint64_t i = 0; i < n_reads; ++i) {
-    if (s.h_len[i] > stride) return fail(QK_EINVAL, "read %llu is longer than the stride", (unsigned long long)i);
-    max_len = std::max(max_len, s.h_len[i]);
+    const uint32_t l = s.h_len[i];
+    if (l > stride) return fail(QK_EINVAL, "read %llu is longer than the stride", (unsigned long long)i);
+    max_len = std::max(max_len, l);
+    // the promise is checked where that is cheap — the first and the last pad byte of every read (the host has the bytes)
+    if ((flags & QK_BATCH_NEUTRAL_PADS) && l < stride) {
+      const uint8_t *ps = s.h_seq + i * (uint64_t)stride, *pq = s.h_qual + i * (uint64_t)stride;
+      if ((ps[l] & ps[stride - 1] & pq[l] & pq[stride - 1]) != 0xFF)
+        return fail(QK_EINVAL, "read %llu: QK_BATCH_NEUTRAL_PADS promised 0xFF behind the read's last base", (unsigned long long)i);
+    }
   }
   a->held_slot = -1;
   a->next_slot ^= 1;
@@ -1615,7 +1648,7 @@ int qk_accum_commit_strided(qk_accum *a, uint64_t n_reads, uint32_t stride) {
   QK_HIP(hipMemcpyAsync(s.d_seq, s.h_seq, total + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
   QK_HIP(hipMemcpyAsync(s.d_qual, s.h_qual, total + QK_TAIL_SLACK, hipMemcpyHostToDevice, s.stream));
   QK_HIP(hipMemcpyAsync(s.d_len, s.h_len, n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
-  rc = enqueue_batch(a, s.d_seq, s.d_qual, nullptr, s.d_hit, n_reads, total, max_len, s.stream, s.d_len, 0, stride);
+  rc = enqueue_batch(a, s.d_seq, s.d_qual, nullptr, s.d_hit, n_reads, total, max_len, s.stream, s.d_len, flags, stride);
   if (rc) return rc;
   QK_HIP(hipEventRecord(s.done, s.stream));
   s.busy = true;

@@ -355,7 +355,7 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       /* all of one length after all: a fixed-length batch — plain when the stride is that length, padded
        * (qk_accum_commit_padded: uniform reads whose length is not a multiple of 4) when it is the next multiple of 4 */
       if (uniform ? qk_accum_commit_padded(acc, (uint64_t)n, uniform, stride)
-                  : qk_accum_commit_strided(acc, (uint64_t)n, stride)) {
+                  : qk_accum_commit_strided_flags(acc, (uint64_t)n, stride, QK_BATCH_NEUTRAL_PADS)) {   /* (the fill wrote 0xFF pads) */
         host_fail("%s", qk_last_error());
         goto out;
       }

@@ -49,7 +49,9 @@ int64_t qkh_reader_fill_gapped(qkh_reader *r, uint8_t *seq, uint8_t *qual,
 /* Same, into a strided batch (qk_accum_commit_strided): read i is written at
  * i * stride and is lengths[i] long.  The batch ends in front of the first read
  * longer than the stride (it waits for the next batch: qkh_reader_parked_len);
- * returns 0 without consuming anything when that read is the first one. */
+ * returns 0 without consuming anything when that read is the first one.  The
+ * bytes behind a read's last base, up to the stride, are set to 0xFF in both
+ * arrays (QK_BATCH_NEUTRAL_PADS). */
 int64_t qkh_reader_fill_strided(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint32_t *lengths,
                                 uint64_t cap_bytes, uint64_t cap_reads, uint32_t stride,
                                 uint32_t *uniform_len);

@@ -292,6 +292,15 @@ static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *
                           uint32_t *uniform_len, uint64_t stride) {
   uint64_t n = 0, total = 0;   /* total = end of the last read */
   int64_t common = -1;         /* -1 unknown, -2 mixed */
+  /* strided batches: the bytes behind a read's last base, up to the stride, are set to 0xFF in both arrays — neutral to the
+   * kernels (QK_BATCH_NEUTRAL_PADS in quack_hip.h), which then need no tail masks */
+#define PAD_FF(at_, len_)                                                         \
+  do {                                                                            \
+    if (stride && (uint64_t)(len_) < stride) {                                    \
+      memset(seq + (at_) + (len_), 0xFF, (size_t)(stride - (uint64_t)(len_)));    \
+      memset(qual + (at_) + (len_), 0xFF, (size_t)(stride - (uint64_t)(len_)));   \
+    }                                                                             \
+  } while (0)
   if (stride && cap_reads > cap_bytes / stride) cap_reads = cap_bytes / stride;
   if (r->have_parked) {
     if (stride && r->park_len > stride) {     /* the caller has to pick another layout first */
@@ -305,6 +314,7 @@ static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *
     else memset(qual, 0, r->park_len);
     if (starts) starts[0] = 0;
     if (lengths) lengths[0] = (uint32_t)r->park_len;
+    PAD_FF(0, r->park_len);
     total = r->park_len;
     n = 1;
     common = (int64_t)r->park_len;
@@ -319,6 +329,7 @@ static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *
       if (fl > 0xFFFFFFFFull) return -4;
       if (starts) starts[n] = at;
       if (lengths) lengths[n] = (uint32_t)fl;
+      PAD_FF(at, fl);
       n++;
       total = at + fl;
       if (common == -1) common = (int64_t)fl;
@@ -350,11 +361,13 @@ static int64_t fill_batch(qkh_reader *r, uint8_t *seq, uint8_t *qual, uint64_t *
       if ((uint64_t)l > 0xFFFFFFFFull) return -4;
       lengths[n] = (uint32_t)l;
     }
+    PAD_FF(at, l);
     n++;
     total = at + (uint64_t)l;
     if (common == -1) common = l;
     else if (common != l) common = -2;
   }
+#undef PAD_FF
   *extent = total;
   *uniform_len = (common > 0 && common <= 0x7FFFFFFF) ? (uint32_t)common : 0;
   return (int64_t)n;

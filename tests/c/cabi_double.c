@@ -38,7 +38,7 @@ struct qk_accum {
   uint32_t *len[2];
   int next, held;
   uint64_t cap_bytes, cap_reads;
-  unsigned long commits, gapped_commits, aligned_commits, strided_commits, padded_commits, copied_submits, resizes;
+  unsigned long commits, gapped_commits, aligned_commits, strided_commits, padded_commits, copied_submits, resizes, neutral_commits;
 };
 
 int qk_accum_create(qk_accum **out, int device, const uint32_t *bits, uint64_t hint) {
@@ -68,8 +68,8 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *bits, uint64_t h
 void qk_accum_destroy(qk_accum *a) {
   if (!a) return;
   if (getenv("QK_DOUBLE_VERBOSE"))
-    fprintf(stderr, "[double] commits %lu gapped %lu aligned %lu strided %lu copied %lu resized %lu padded %lu\n", a->commits, a->gapped_commits,
-            a->aligned_commits, a->strided_commits, a->copied_submits, a->resizes, a->padded_commits);
+    fprintf(stderr, "[double] commits %lu gapped %lu aligned %lu strided %lu copied %lu resized %lu padded %lu neutral %lu\n", a->commits, a->gapped_commits,
+            a->aligned_commits, a->strided_commits, a->copied_submits, a->resizes, a->padded_commits, a->neutral_commits);
   for (int i = 0; i < 2; i++) {
     free(a->seq[i]);
     free(a->qual[i]);
@@ -171,13 +171,19 @@ int qk_accum_commit_gapped(qk_accum *a, uint64_t n, uint64_t extent, uint32_t fl
   return QK_OK;
 }
 
-int qk_accum_commit_strided(qk_accum *a, uint64_t n, uint32_t stride) {
+int qk_accum_commit_strided_flags(qk_accum *a, uint64_t n, uint32_t stride, uint32_t flags) {
   if (a->held < 0) return fail(QK_ESTATE, "no batch acquired");
   const int s = a->held;
   if (stride == 0 || (stride & 3u)) return fail(QK_EINVAL, "stride must be a multiple of 4");
+  if (flags & ~QK_BATCH_NEUTRAL_PADS) return fail(QK_EINVAL, "unknown flags");
   if (n * (uint64_t)stride > a->cap_bytes || n > a->cap_reads) return fail(QK_EINVAL, "batch exceeds slot capacity");
-  for (uint64_t i = 0; i < n; i++)
+  for (uint64_t i = 0; i < n; i++) {
     if (a->len[s][i] > stride) return fail(QK_EINVAL, "read longer than the stride");
+    /* the double holds the producer to its promise for EVERY pad byte */
+    for (uint32_t k = a->len[s][i]; (flags & QK_BATCH_NEUTRAL_PADS) && k < stride; k++)
+      if (a->seq[s][i * stride + k] != 0xFF || a->qual[s][i * stride + k] != 0xFF) return fail(QK_EINVAL, "a pad byte is not 0xFF");
+  }
+  a->neutral_commits += (flags & QK_BATCH_NEUTRAL_PADS) != 0;
   release(a);
   a->commits++;
   a->strided_commits++;
@@ -185,6 +191,8 @@ int qk_accum_commit_strided(qk_accum *a, uint64_t n, uint32_t stride) {
     oracle_accumulate_read(&a->t, a->seq[s] + i * stride, a->qual[s] + i * stride, a->len[s][i], a->kmers);
   return QK_OK;
 }
+
+int qk_accum_commit_strided(qk_accum *a, uint64_t n, uint32_t stride) { return qk_accum_commit_strided_flags(a, n, stride, 0u); }
 
 /* padded fixed-length batches: the double wants them for uniform reads whose length is not a multiple of 4 when
  * adapters are loaded (the product's rule), or for every such length with QK_DOUBLE_PAD_ALWAYS */

@@ -917,9 +917,43 @@ def test_strided_batches(n, lo, hi, stride, adapters):
         d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
         d_l = torch.from_numpy(lens.astype(np.int32)).cuda()
         acc.submit_device_strided(d_s, d_q, d_l, n, stride, int(lens.max()))
+        # round 4: 0xFF behind every read and the producer's promise of it (QK_BATCH_NEUTRAL_PADS): the kernel without tail
+        # masks, content[A] from the lengths counted in the loop; device-resident and through a pinned slot
+        s3, q3, _ = strided_from_ragged(seq, qual, off, stride, fill=0xFF)
+        d_s3, d_q3 = torch.from_numpy(pad_for_device(s3)).cuda(), torch.from_numpy(pad_for_device(q3)).cuda()
+        acc.submit_device_strided(d_s3, d_q3, d_l, n, stride, int(lens.max()), neutral_pads=True)
         sd = acc.finish()
-    assert sd.number_of_sequences == 2 * want[1]
-    assert_same((sd.bases, want[1]), (2 * want[0], want[1]))
+    assert sd.number_of_sequences == 3 * want[1]
+    assert_same((sd.bases, want[1]), (3 * want[0], want[1]))
+
+
+def test_neutral_pads_promise_is_checked_where_the_host_has_the_bytes():
+    """qk_accum_commit_strided_flags(QK_BATCH_NEUTRAL_PADS) looks at the first and the last pad byte of every read"""
+    import ctypes
+    from quack_amd import _capi
+    n, stride = 1000, 152
+    lens = np.full(n, 140, np.uint32)
+    with quack_amd.Accumulator(0) as acc:
+        for spoil in (None, 140, 151):
+            hs, hq, _ = acc.acquire()
+            hl = ctypes.POINTER(ctypes.c_uint32)()
+            assert acc._L.qk_accum_slot_lengths(acc._h, ctypes.byref(hl)) == 0
+            np.ctypeslib.as_array(hl, shape=(n,))[:] = lens
+            hs[:n * stride] = 0xFF
+            hq[:n * stride] = 0xFF
+            hs[:n * stride].reshape(n, stride)[:, :140] = ord("C")
+            hq[:n * stride].reshape(n, stride)[:, :140] = ord("5")
+            if spoil is not None:
+                hq[500 * stride + spoil] = ord("I")
+            rc = acc._L.qk_accum_commit_strided_flags(acc._h, n, stride, _capi.QK_BATCH_NEUTRAL_PADS)
+            if spoil is None:
+                assert rc == 0
+            else:
+                assert rc != 0 and b"0xFF" in acc._L.qk_last_error()
+                acc._L.qk_accum_commit(acc._h, 0, 0, 0, 0)      # give the slot back
+        sd = acc.finish()
+    assert sd.number_of_sequences == n and sd.bases[:140, 20].sum() == 140 * n and sd.bases[:140, 93].sum() == 140 * n
+    assert sd.bases[139, 95] == n and sd.bases.shape[0] == 140
 
 
 def test_strided_rejects_bad_geometry():

@@ -118,6 +118,7 @@ def test_trimmed_short_reads_switch_to_strided_batches(quack_double, tmp_path):
         assert a.stdout == b.stdout and len(a.stdout) > 1000
         commits, gapped, aligned, strided = stats(a)[:4]
         assert gapped == 0 and strided >= commits - 6 and strided > 10, a.stderr
+        assert stats(a)[7] == strided       # every strided batch with 0xFF behind its reads (the double checks every pad byte)
         assert stats(b)[3] == 0
 
 
@@ -154,7 +155,7 @@ def test_uniform_reads_of_an_odd_length_are_laid_out_at_a_padded_stride(quack_do
         n_acc = len(extra.get("QUACK_DEVICES", "0").split(","))
         assert stats(a)[6] >= stats(a)[0] - n_acc and stats(a)[3] == 0, a.stderr        # all but the first batch (of every accumulator's turn)
         assert stats(b)[6] == 0 and stats(c)[6] == 0 and stats(d)[6] > 5
-        assert sum(int(l.split()[-1]) for l in e.stderr.decode().splitlines() if l.startswith("[double]")) > 0, e.stderr   # (any accumulator)
+        assert sum(int(l.split("padded")[1].split()[0]) for l in e.stderr.decode().splitlines() if l.startswith("[double]")) > 0, e.stderr   # (any accumulator)
     # 150s, then a stretch trimmed to 120-149 (strided batches at the same stride), then reads of 20-150 (packed again)
     lens = np.concatenate([[150] * 1500, np.where(g.random(1500) < 0.6, 150, g.integers(120, 150, 1500)), g.integers(20, 151, 1500),
                            [150] * 1500])

@@ -118,7 +118,15 @@ def fuzz(seconds, seed, rounds=1 << 30, log=print):
                 s2, q2 = np.full(n * stride, ord("G"), np.uint8), np.full(n * stride, 40, np.uint8)
                 idx = np.repeat(np.arange(n, dtype=np.int64) * stride - off[:-1].astype(np.int64), lens) + np.arange(total)
                 s2[idx], q2[idx] = seq, qual
-                acc.submit_strided(s2, q2, lens.astype(np.uint32), stride)
+                if route == 2:     # 0xFF behind every read, promised (QK_BATCH_NEUTRAL_PADS), device-resident
+                    how = "submit_device_strided neutral pads, stride %d" % stride
+                    s2[:], q2[:] = 0xFF, 0xFF
+                    s2[idx], q2[idx] = seq, qual
+                    d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
+                    d_l = torch.from_numpy(lens.astype(np.int32)).cuda()
+                    acc.submit_device_strided(d_s, d_q, d_l, n, stride, int(lens.max()), neutral_pads=True)
+                else:
+                    acc.submit_strided(s2, q2, lens.astype(np.uint32), stride)
             sd = acc.finish()
         ok = sd.number_of_sequences == want[1] and sd.bases.shape == want[0].shape and np.array_equal(sd.bases, want[0])
         if not ok:
