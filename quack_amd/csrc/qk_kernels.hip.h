@@ -577,6 +577,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     // grouped rows: position pp of the reads lives in the columns pp, pp + gstride, ... (one per read of a row); summed here
     const uint32_t span = (GROUPS && GRP > 1u) ? p.read_len : TP;
+    // (every workgroup starting at another row — same-address queueing at the L2 — was measured again in round 4, also on 0.2 ms
+    // launches of 36 bp reads where the workgroups do finish in step: nothing, 0.1864 / 0.1847 ms)
     for (uint32_t row = 33u + wave; row <= 123u; row += T / 64) {  // quack.c:203: bin = byte - 33
       for (uint32_t pp = lane; pp < span; pp += 64u) {
         uint32_t c = 0;
