@@ -1075,6 +1075,58 @@ def test_host_feed_lays_trimmed_reads_out_at_a_fixed_stride(tmp_path, monkeypatc
         assert_same((sd.bases, sd.number_of_sequences), want)
 
 
+def test_host_feed_lays_uniform_150bp_reads_out_at_a_padded_stride(tmp_path, monkeypatch):
+    """whole-file path on the metric's own input with the adapter scan (round 4): uniform 150 bp reads — from the second batch
+    on, and for the batches parsed while the accumulators start, the tokenizer writes them 152 bytes apart and commits padded
+    fixed-length batches (rows of two reads, 16 positions per lane); a stretch of trimmed reads in the middle goes on as strided
+    batches with 0xFF pads, a stretch of very ragged ones as packed batches.  Same counters as the oracle's read_fastq, as the
+    packed feed (QUACK_NO_STRIDE=1), through three accumulators, as a .gz, and byte-identical SVG from the CLI"""
+    monkeypatch.setenv("QUACK_HIP_BATCH_MB", "1")
+    rng = np.random.default_rng(15)
+    lens = np.concatenate([np.full(30000, 150), np.where(rng.random(12000) < 0.6, 150, rng.integers(125, 150, 12000)),
+                           rng.integers(30, 151, 8000), np.full(20001, 150)])
+    n = len(lens)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(off[-1])
+    ads = synth.synthetic_adapters()
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, total)].copy()
+    qual = (33 + rng.integers(2, 42, total)).astype(np.uint8)
+    for r in range(0, n, 4):
+        a, e = int(off[r]), int(off[r + 1])
+        ad = np.frombuffer(ads[r % len(ads)], np.uint8)
+        at = a + int(rng.integers(0, e - a - 11))
+        m = min(len(ad), e - at)
+        seq[at:at + m] = ad[:m]
+    fq = tmp_path / "u150.fq"
+    with open(fq, "wb") as f:
+        for r in range(n):
+            a, b = int(off[r]), int(off[r + 1])
+            f.write(b"@r%d\n" % r + seq[a:b].tobytes() + b"\n+\n" + qual[a:b].tobytes() + b"\n")
+    fa = tmp_path / "ads.fa"
+    with open(fa, "wb") as f:
+        for i, a in enumerate(ads):
+            f.write(b">a%d\n" % i + a + b"\n")
+    k = ob.kmers_from_file(str(fa))
+    bits = quack_amd.read_adapters(str(fa))
+    assert np.array_equal(bits, ob.kmers_to_bitset(k))
+    want = ob.read_fastq(str(fq), k)
+    assert want[1] == n and want[0][:, 96].sum() > 10000
+    subprocess.check_call(["gzip", "-k", "-1", str(fq)])
+    for env in ({}, {"QUACK_NO_STRIDE": "1"}, {"QUACK_NO_EARLY": "1"}, {"QUACK_HIP_NO_NEUTRAL": "1"}):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        sd = quack_amd.read_fastq(str(fq), bits)
+        assert_same((sd.bases, sd.number_of_sequences), want)
+        for kk in env:
+            monkeypatch.delenv(kk)
+    sd3 = quack_amd.read_fastq(str(fq) + ".gz", bits, devices=(0, 0, 0))
+    assert_same((sd3.bases, sd3.number_of_sequences), want)
+    quack = os.path.join(cases.ROOT, "quack_amd", "host", "quack")
+    svgs = [subprocess.run([quack, "-u", str(fq), "-a", str(fa)], capture_output=True, env=dict(os.environ, **e), timeout=300)
+            for e in ({}, {"QUACK_NO_STRIDE": "1", "QUACK_HIP_UNFUSED_ADAPTERS": "1"})]
+    assert svgs[0].returncode == 0 and svgs[0].stdout == svgs[1].stdout and svgs[0].stdout.startswith(b"<svg")
+
+
 # ---------------------------------------------------------------- long ragged reads: reach sort + static split
 @pytest.mark.parametrize("n,lo,hi,adapters", [(50, 1000, 20000, False), (300, 5000, 5000, False), (3000, 0, 9000, True),
                                               (700, 2049, 2049, False), (40000, 1500, 3000, False), (257, 511, 40000, True),
