@@ -363,7 +363,10 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
        * packed batches */
       parked = qkh_reader_parked_len(rd);
       if (parked > stride) stride = parked <= 512 ? (uint32_t)((parked + 3) & ~3ull) : 0;
-      else if (n > 0 && !uniform) {
+      else if (n > 0 && uniform) {
+        /* (a stride that one long read widened earlier comes back down once the batches are uniform again) */
+        if (((uniform + 3u) & ~3u) < stride) stride = (uniform + 3u) & ~3u;
+      } else if (n > 0 && !uniform) {
         /* (no longer "nearly one length" — mean below 3/4 of the stride: the padding would be a third of the traffic) */
         uint64_t sum = 0;
         for (int64_t i = 0; i < n; i++) sum += lengths[i];
