@@ -26,7 +26,9 @@ host: $(LIB_HIP)
 oracle:
 	$(MAKE) -C oracle
 
-tools: tools/kbench tools/gen_fastq tools/inflate_bench
+tools: tools/kbench tools/gen_fastq tools/inflate_bench tools/feed_bench
+tools/feed_bench: tools/feed_bench.c host
+	$(CC) -O3 -o $@ tools/feed_bench.c -Iinclude -I$(HOST) -Lquack_amd -lquack_host -lquack_hip -Wl,-rpath,'$$ORIGIN/../quack_amd'
 tools/inflate_bench: tools/inflate_bench.c $(HOST)/inflate_fast.c $(HOST)/inflate_body.inc $(HOST)/inflate_fast.h $(HOST)/crc32_fold.c
 	$(CC) -O3 -o $@ tools/inflate_bench.c $(HOST)/inflate_fast.c $(HOST)/crc32_fold.c -I$(HOST) -lz
 tools/gen_fastq: tools/gen_fastq.c
@@ -35,6 +37,6 @@ tools/kbench: tools/kbench.cpp $(CSRC)/qk_shim.hip $(KERNEL_HDRS) include/quack_
 	$(HIPCC) $(HIPFLAGS) -DQK_ABLATION -o $@ tools/kbench.cpp $(CSRC)/qk_shim.hip -ldl
 
 clean:
-	rm -f $(LIB_HIP) tools/kbench tools/gen_fastq tools/inflate_bench
+	rm -f $(LIB_HIP) tools/kbench tools/gen_fastq tools/inflate_bench tools/feed_bench
 	-$(MAKE) -C $(HOST) clean
 	-$(MAKE) -C oracle clean

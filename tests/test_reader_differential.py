@@ -111,6 +111,54 @@ def test_wellformed_records_gz_multimember(tmp_path_factory, shape, seed):
     assert len(got) == len(shape)
 
 
+def hostile_big(seed, n=20000):
+    """a large FASTQ (several source blocks, line index in use) with everything the general parser handles sprinkled into
+    long runs of plain four-line records"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        ln = int(rng.integers(1, 300))
+        s = "".join(rng.choice(list("ACGTNacgt"), ln))
+        q = "".join(chr(33 + int(v)) for v in rng.integers(0, 60, ln))
+        kind = rng.integers(0, 400)
+        if kind == 0 and ln > 6:
+            out.append("@r%d\n%s\n%s\n+\n%s\n%s\n" % (i, s[:ln // 2], s[ln // 2:], q[:5], q[5:]))     # multi-line
+        elif kind == 1:
+            out.append("@r%d\r\n%s\r\n+\r\n%s\r\n" % (i, s, q))                                      # CRLF
+        elif kind == 2:
+            out.append("\n\n@r%d x y\n%s\n+r%d again\n%s\n" % (i, s, i, q))                             # blank lines, text on both header lines
+        elif kind == 3:
+            out.append(">f%d\n%s\n" % (i, s))                                                             # a FASTA record in between
+        elif kind == 4 and ln > 1:
+            out.append("@r%d\n%s\n+\n@%s\n" % (i, s, q[1:]))                                             # a quality line that starts with '@'
+        else:
+            out.append("@r%d\n%s\n+\n%s\n" % (i, s, q))
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("form", ["plain", "gz"])
+def test_large_hostile_files(tmp_path, form):
+    """round 4: 20,000 records with anomalies between long runs of plain ones, plain and as a two-member .gz, at three batch
+    geometries; the second file ends at a malformed record two thirds in (quack.c:193: the stream stops there)"""
+    for seed in (1, 2):
+        data = hostile_big(seed)
+        if seed == 2:
+            cut = data.index(b"@r13000\n")
+            data = data[:cut] + b"@bad\nACGTACGT\n+\nIIII\n" + data[cut:]
+        p = tmp_path / ("h%d.fq%s" % (seed, ".gz" if form == "gz" else ""))
+        if form == "gz":
+            with open(p, "wb") as f:
+                third = len(data) // 3
+                f.write(gzip.compress(data[:third], 1) + gzip.compress(data[third:], 1))
+        else:
+            p.write_bytes(data)
+        want = oracle_tokenize(str(p))
+        assert len(want) > 12000
+        for cap_bytes, cap_reads in ((1 << 20, 1 << 16), (70000, 300), (1 << 20, 1000)):
+            got, _ = product_tokenize(str(p), cap_bytes, cap_reads)
+            assert got == want, (seed, cap_bytes, cap_reads)
+
+
 def test_adapter_table_matches_oracle():
     import quack_amd
     for f in ("adapters.fa", "adapters.fa.gz", "kat_adapter.fa"):
