@@ -33,6 +33,7 @@
 #include "pinflate.h"
 
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
 #include "inflate_fast.h"
@@ -72,7 +73,7 @@ struct qkh_pinflate {
   unsigned tail;         /* slices consumed */
   int holding, stop, failed;
   /* the chain: state of the stream in front of slice `chain_next` */
-  unsigned chain_next;
+  _Atomic unsigned chain_next;   /* (written under mu; the slice whose turn is next also watches it without) */
   uint64_t chain_bit;
   uint8_t chain_win[WIN];
   size_t chain_win_len, chain_member_out;
@@ -192,7 +193,13 @@ static void *worker_main(void *arg) {
     memset(&sp, 0, sizeof sp);
     if (k > 0) speculate(p, k, s, z, &sp);
 
-    /* ---- my turn in the chain */
+    /* ---- my turn in the chain.  The slice that is next (or next but one) does not sleep: waking a thread through the condition
+     * variable took longer than the hand-over itself (resolving 32 KiB), and the chain is the one thing nothing overlaps */
+    for (int spins = 0; spins < 20000; spins++) {
+      const unsigned cn = atomic_load_explicit(&p->chain_next, memory_order_acquire);
+      if (cn == k || k - cn > 2u) break;
+      __builtin_ia32_pause();
+    }
     pthread_mutex_lock(&p->mu);
     while (!p->stop && p->chain_next != k) pthread_cond_wait(&p->cv, &p->mu);
     if (p->stop) {

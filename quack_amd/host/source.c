@@ -506,9 +506,19 @@ static int n_cpus(void) {
   return (int)n;
 }
 
-static size_t pgzip_slice(void) {
+/* Compressed bytes per slice of the multi-threaded inflate (pinflate.c).  Every slice costs the chain a hand-over — the last 32 KiB
+ * resolved, the window copied, the next slice's thread woken — which nothing overlaps: on the GPU box's host config 2's file
+ * (1.7 GB, 32 threads, tools/feed_bench) took 0.52 s at 512 KiB, 0.41 at 1 MiB, 0.40 at 2 MiB, 0.36 at 4 MiB and 8 MiB.  So: as
+ * large as leaves every thread eight slices, between 1 and 4 MiB (a slot holds ~15 bytes per compressed byte: 60 MB at 4 MiB). */
+static size_t pgzip_slice(size_t file_len, int threads) {
   const char *e = getenv("QUACK_PGZIP_CHUNK_KB");
-  return e && atoi(e) > 0 ? (size_t)atoi(e) << 10 : (size_t)1 << 20;
+  size_t s;
+  if (e && atoi(e) > 0) return (size_t)atoi(e) << 10;
+  s = file_len / ((size_t)(threads > 0 ? threads : 1) * 8u);
+  s &= ~(((size_t)256 << 10) - 1u);
+  if (s < ((size_t)1 << 20)) s = (size_t)1 << 20;
+  if (s > ((size_t)4 << 20)) s = (size_t)4 << 20;
+  return s;
 }
 
 qkh_source *qkh_source_open(const char *path) {
@@ -554,8 +564,8 @@ qkh_source *qkh_source_open(const char *path) {
         if (bgzf_member_size(s->map, s->map + s->map_len) && !getenv("QUACK_NO_BGZF")) {
           workers = n_cpus();
           snprintf(s->kind, sizeof s->kind, "bgzf x%d", workers);
-        } else if (n_cpus() > 1 && !getenv("QUACK_NO_PGZIP") && s->map_len >= 2 * pgzip_slice()) {
-          s->pz = qkh_pinflate_open(s->map, s->map_len, n_cpus(), pgzip_slice());
+        } else if (n_cpus() > 1 && !getenv("QUACK_NO_PGZIP") && s->map_len >= 2 * pgzip_slice(0, 1)) {
+          s->pz = qkh_pinflate_open(s->map, s->map_len, n_cpus(), pgzip_slice(s->map_len, n_cpus()));
           if (!s->pz) goto fail;
           snprintf(s->kind, sizeof s->kind, "pgzip x%d", n_cpus());
           s->checks = 1;
