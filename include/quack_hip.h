@@ -161,8 +161,9 @@ int qk_accum_commit_strided(qk_accum *acc, uint64_t n_reads, uint32_t stride);
  * the kernel runs without tail masks (a third of its instructions; 10M trimmed 150 bp reads 0.5300 -> 0.5178 ms); a position's content[A] comes from the lengths the kernel counts anyway.  The host tokenizer writes its strided
  * batches that way (quack_amd/host/reader.c) and qk_accum_submit_strided neutralises the pads on its way into the pinned
  * slot.  The pinned-slot commit checks the first and the last pad byte of every read (QK_EINVAL otherwise); a
- * device-resident batch is taken at its word — pads that are not 0xFF would be counted.  Same counters as without
- * the flag. */
+ * device-resident batch is taken at its word — pads that are not 0xFF would be counted — unless QUACK_HIP_CHECK_PADS=1 is
+ * set: the shim then checks every pad byte on the device first, and a violation fails the next qk_accum_sync (tests,
+ * debugging a producer).  Same counters as without the flag. */
 #define QK_BATCH_NEUTRAL_PADS 2u
 int qk_accum_submit_device_strided_flags(qk_accum *acc, const void *d_seq, const void *d_qual, const void *d_lengths,
                                          uint64_t n_reads, uint32_t stride, uint32_t max_len, uint32_t flags, void *hip_stream);

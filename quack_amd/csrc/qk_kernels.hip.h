@@ -59,6 +59,7 @@ constexpr uint32_t kMaxReadsPerSlice = 65535; // u16 counters: <=1 hit/read/pos
 // bits of the device status word (HistParams::status), read back by qk_accum_sync
 constexpr uint32_t kStatusNotAligned = 1u;   // a batch submitted as QK_BATCH_ALIGNED128 holds a read off a 128-byte line
 constexpr uint32_t kStatusBadLength = 2u;    // a device-side lengths[] entry exceeds the stride / the table
+constexpr uint32_t kStatusBadPads = 4u;      // a batch submitted as QK_BATCH_NEUTRAL_PADS holds a pad byte that is not 0xFF (checked on request)
 
 // Device-side parameter block of one launch.
 struct HistParams {
@@ -1791,6 +1792,18 @@ __global__ __launch_bounds__(256) void strided_starts_kernel(unsigned long long 
     bad |= lengths[i] > len_limit;
   }
   if (bad) atomicOr(status, kStatusBadLength);
+}
+
+// QK_BATCH_NEUTRAL_PADS on a device-resident batch is a promise the kernels take at its word; QUACK_HIP_CHECK_PADS=1 makes the
+// shim look first (tests, debugging a producer): every byte of [length, stride) of every read, both arrays
+__global__ __launch_bounds__(256) void pads_check_kernel(const uint8_t *seq, const uint8_t *qual, const uint32_t *lengths, uint64_t n,
+                                                         uint32_t stride, uint32_t *status) {
+  bool bad = false;
+  for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (uint64_t)gridDim.x * 256) {
+    const uint32_t len = lengths[r] < stride ? lengths[r] : stride;
+    for (uint32_t k = len; k < stride; ++k) bad |= seq[r * stride + k] != 0xFFu || qual[r * stride + k] != 0xFFu;
+  }
+  if (bad) atomicOr(status, kStatusBadPads);
 }
 
 // table += table32, table32 = 0 (HistParams::table32)

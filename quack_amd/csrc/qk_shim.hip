@@ -725,6 +725,12 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     }
   }
   if ((rc = order_after_previous(a, st))) return rc;
+  if (strided && pl.neutral && getenv("QUACK_HIP_CHECK_PADS")) {   // (the promise, verified on request: see qk::pads_check_kernel)
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, 4096);
+    hipLaunchKernelGGL(qk::pads_check_kernel, dim3(blocks), dim3(256), 0, st, d_seq, d_qual, d_len, n_reads, stride, a->d_status);
+    QK_HIP(hipGetLastError());
+    a->status_armed = true;
+  }
   TimedLaunch tl{};
   // (events around a launch cost ~10 us of stream time: a caller that also measures its own wall
   // clock asks for every Nth batch only)
@@ -1717,6 +1723,8 @@ int qk_accum_sync(qk_accum *a) {
       QK_HIP(hipMemset(a->d_status, 0, sizeof st));
       if (st & qk::kStatusBadLength)
         return fail(QK_EINVAL, "a strided batch holds a read longer than its stride; the counters are unusable");
+      if (st & qk::kStatusBadPads)
+        return fail(QK_EINVAL, "a batch submitted as QK_BATCH_NEUTRAL_PADS holds a pad byte that is not 0xFF; the counters are unusable");
       return fail(QK_EINVAL, "a batch submitted as QK_BATCH_ALIGNED128 holds a read that does not start on a 128-byte boundary; the counters are unusable");
     }
   }

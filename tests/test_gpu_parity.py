@@ -956,6 +956,32 @@ def test_neutral_pads_promise_is_checked_where_the_host_has_the_bytes():
     assert sd.bases[139, 95] == n and sd.bases.shape[0] == 140
 
 
+def test_neutral_pads_promise_on_a_device_batch_can_be_verified(monkeypatch):
+    """a device-resident batch is taken at its word; with QUACK_HIP_CHECK_PADS=1 the shim checks every pad byte first and a
+    violation fails the next sync (and without the check a broken promise is counted — which is what the check is for)"""
+    import torch
+    n, stride = 5000, 152
+    rng = np.random.default_rng(8)
+    lens = rng.integers(100, 151, n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(off[-1]))]
+    qual = (33 + rng.integers(0, 42, int(off[-1]))).astype(np.uint8)
+    want = ob.accumulate_batch(seq, qual, off)
+    s3, q3, l3 = strided_from_ragged(seq, qual, off, stride, fill=0xFF)
+    d_l = torch.from_numpy(l3.astype(np.int32)).cuda()
+    monkeypatch.setenv("QUACK_HIP_CHECK_PADS", "1")
+    with quack_amd.Accumulator(0) as acc:
+        acc.submit_device_strided(torch.from_numpy(pad_for_device(s3)).cuda(), torch.from_numpy(pad_for_device(q3)).cuda(), d_l, n, stride, 150, neutral_pads=True)
+        sd = acc.finish()
+    assert_same((sd.bases, sd.number_of_sequences), want)
+    q3 = q3.copy()
+    q3[3000 * stride + 151] = ord("I")          # one pad byte that is not 0xFF
+    with quack_amd.Accumulator(0) as acc:
+        acc.submit_device_strided(torch.from_numpy(pad_for_device(s3)).cuda(), torch.from_numpy(pad_for_device(q3)).cuda(), d_l, n, stride, 150, neutral_pads=True)
+        with pytest.raises(quack_amd.HipUnavailable, match="0xFF"):
+            acc.sync()
+
+
 def test_strided_rejects_bad_geometry():
     with quack_amd.Accumulator(0) as acc:
         with pytest.raises(quack_amd.HipUnavailable):
