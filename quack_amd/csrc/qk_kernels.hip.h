@@ -233,8 +233,8 @@ constexpr uint32_t kCandWords = 16u * kCandCap * 2u;    // 16 waves x 96 entries
 constexpr uint32_t kCandCap16 = 64;
 constexpr uint32_t kCandWords16 = 16u * kCandCap16 * 4u;
 // First hits of a fixed-length one-tile batch stay in the LDS (round 3): all lanes of a read sit in one workgroup in
-// one step, so min(first hit) needs no global memory — a ring of kFhRing words indexed by the read's place in the
-// slice, folded into the kmer_count row and cleared every G <= kFhRing / 2 reads behind a workgroup barrier (every
+// one step, so min(first hit) needs no global memory — a ring of fh_words (>= kFhRing) words indexed by the read's place in the
+// slice, folded into the kmer_count row and cleared every G <= fh_words / 2 reads behind a workgroup barrier (every
 // wave drains its queue in front of the barrier).  What it replaces: one global atomicMin per read with a hit — 2.9 M
 // per 10M x 300, each a random 128-byte line of a 40 MB array through the L2 and, gfx9 having ONE counter for loads
 // and atomics, inside the wait for the next step's loads — 7-10 % of the kernel, measured by leaving the atomic out;
@@ -411,7 +411,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       reinterpret_cast<char *>(lds_misc + 4u) + ((ADAPT && p.bucket_log2) ? (16u << p.bucket_log2) : 0u));
   const uint32_t SR = STAGED ? p.stage_reads : kStageReads;
   uint32_t *lds_ridx = reinterpret_cast<uint32_t *>(lds_list + SR);   // ADAPT: index of a staged read within its pass
-  uint32_t *lds_fh = reinterpret_cast<uint32_t *>(lds_list);          // ADAPT, FIXED: the first-hit ring (kFhRing words)
+  uint32_t *lds_fh = reinterpret_cast<uint32_t *>(lds_list);          // ADAPT, FIXED: the first-hit ring (HistParams::fh_words words)
 
   const uint64_t TL = p.table_len;
   // grouped rows (HistParams::group): built into the one variant the planner uses them with
