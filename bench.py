@@ -87,6 +87,10 @@ WORKLOADS = {
     "trimmedmasked": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7, stride=152,
                           label="10M-read synthetic trimmed 150 bp FASTQ (70% full length, rest 120-149), fixed stride 152 + "
                                 "per-read lengths, arbitrary bytes behind the reads (the kernel masks the tails)"),
+    # experiment: what a tile-major layout of long reads would stream like — 512-byte rows (the pieces of 1-20 kb reads: 95 % full,
+    # the last piece of a read shorter), one strided launch with neutral pads ("next for long reads")
+    "rows512": dict(n=2_930_000, L=512, ragged=(1, 512), adapters=False, full=0.95, stride=512, neutral=True,
+                    label="experiment: 2.93M rows of 512 bytes (95% full), fixed stride 512 + per-row lengths, 0xFF pads"),
     "trimmedpacked": dict(n=10_000_000, L=150, ragged=(120, 150), adapters=False, full=0.7,
                           label="10M-read synthetic trimmed 150 bp FASTQ (70% full length, rest 120-149), packed ragged"),
 }
