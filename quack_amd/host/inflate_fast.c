@@ -25,7 +25,7 @@
 
 #define LITLEN_BITS 11
 #define DIST_BITS 8
-#define MULTI_BITS 12   /* index width of the literal-run table (qkh_inflate::multi) */
+#define MULTI_BITS QKH_MULTI_BITS
 #define MAX_CODE_LEN 15
 
 /* table entry: bits 0-4 code length to consume, 5-7 kind, 8-12 extra bits

@@ -6,6 +6,9 @@
 #include <stdint.h>
 
 enum { QKH_LITLEN_TABLE = 2048 + 4096, QKH_DIST_TABLE = 256 + 2048 };
+#ifndef QKH_MULTI_BITS
+#define QKH_MULTI_BITS 12   /* index width of the literal-run table (qkh_inflate::multi); 13 measured slower on both hosts */
+#endif
 enum { QKH_Z_MEMBER, QKH_Z_BLOCK, QKH_Z_STORED, QKH_Z_CODES, QKH_Z_TRAILER, QKH_Z_DONE, QKH_Z_ERROR };
 
 /* A member trailer met while decoding: `off` output elements into the CALL that met it
@@ -50,7 +53,7 @@ typedef struct {
    * are decoded (not when its header is parsed: the search for block starts parses many headers it never decodes). */
   const uint32_t *multi;
   int fixed_multi_ready, dyn_multi_ready;
-  uint32_t fixed_multi[4096], dyn_multi[4096];
+  uint32_t fixed_multi[1 << QKH_MULTI_BITS], dyn_multi[1 << QKH_MULTI_BITS];
 } qkh_inflate;
 
 /* The member ends of one delivered chunk of output (a ring block, a pinflate slice) and the
