@@ -519,6 +519,15 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   // strided kernel's 94 VALU instructions per chunk; the kernel is mostly bound by how its three load streams arrive, so the
   // gain is 2.3 % (10M trimmed 150 bp reads 0.5300 -> 0.5178 ms in one process, 0.696 -> 0.712 of peak).
   constexpr bool FAST_FIXED = FIXED && (!SV || NP);   // no tail masks
+  // LUTV (round 5; the fused adapter scan on fixed-length reads, 16 positions per lane — the VALU-bound variant): base codes by
+  // table lookup (v_perm_b32) instead of three SWAR indicators per dword, see consume
+  constexpr bool LUTV = W16 && ADAPT && FIXED && !SV && MODE == 0;
+  // code table, selector (byte >> 1) & 7: A 000 -> 3, C 001 -> 1, T 010 -> 2, G 011 -> 0, 100 .. 111 (H-O, X-_, N) -> 3
+  constexpr uint32_t lut_cc_lo = 0x00020103u, lut_cc_hi = 0x03030303u;
+  // the five-bit key (byte & 31) the classes 001 / 010 / 011 must have for that code to be quack.c:150's: C = 3, T = 20, G = 7
+  constexpr uint32_t lut_k5 = 0x07140300u;
+  // code -> "is T" (2), "is C" (1) as 0 / 1 bytes
+  constexpr uint32_t lut_is_t = 0x00010000u, lut_is_c = 0x00000100u;
   constexpr bool UNIFORM = FIXED && !SV;              // every read one length: lengths in closed form
   uint32_t events = 0, steps_v = 0;
   uint32_t fixed_mask = 0;   // FIXED: which of the lane's 8K positions are bases of a read (the same for every row): bit i = position cpos + i
@@ -538,9 +547,13 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         uint32_t g = (acc_g[d] >> (8 * b)) & 0xFFu;
         {
           const uint32_t ev = FAST_FIXED ? steps_v : events;
-          t = ev - t;
-          c = ev - c;
-          g = ev - g;
+          if constexpr (LUTV) {   // acc_t / acc_c count the T / C bytes themselves, acc_g the bytes that are A-like or C
+            g = ev - g - t;
+          } else {
+            t = ev - t;
+            c = ev - c;
+            g = ev - g;
+          }
         }
         if (t) lds_add(lds_base, off + 4u * TP, t);
         if (c) lds_add(lds_base, off + 8u * TP, c);
@@ -1063,6 +1076,33 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         if (FAST_FIXED && !ADAPT && nl == 0) continue;   // per lane: past the end of the slice (its last step only)
         uint32_t own16K[K];
         const bool count_me = !FAST_FIXED || nl != 0;   // ragged: every lane (masked bytes take care of themselves)
+        // LUTV (round 5): the complemented 2-bit code of every base byte (A and everything else 3, T 2, C 1, G 0) straight
+        // from the byte — bits 3..1 of A, C, G, T, N (either case) are 000, 001, 011, 010, 111, so (byte >> 1) & 7 is the
+        // selector of a v_perm_b32 whose two source registers are an 8-entry table: four bases per instruction.  Those three
+        // bits decide every byte's code correctly EXCEPT the other members of the classes 001 / 010 / 011 (B R S, D E U,
+        // F V W and the non-letters that share their low five bits), which quack.c:150 maps to A: a second table holds the
+        // five-bit key a class must have (3, 20, 7; 0 = any), and v_msad_u8 — the sum of absolute differences over the bytes
+        // whose reference is not 0 — adds up the violations of a whole step in one register.  A wave that meets one (IUPAC
+        // codes; real reads hold A C G T N) recomputes the step's codes from the exact "not T / not C / not G" indicators.
+        // What it replaces: three indicators per dword (13 VALU) + three v_dot4 per dword to pack them; now 6 + 1.
+        uint32_t ccU[2 * K] = {};
+        if constexpr (LUTV) {
+          const uint32_t sd[4] = {s[u].x, s[u].y, s[u].z, s[u].w};
+          uint32_t bad = 0u;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const uint32_t key = (sd[d] >> 1) & 0x07070707u;
+            ccU[d] = __builtin_amdgcn_perm(lut_cc_hi, lut_cc_lo, key);
+            bad = __builtin_amdgcn_msad_u8(sd[d] & 0x1F1F1F1Fu, __builtin_amdgcn_perm(0u, lut_k5, key), bad);
+          }
+          if (__builtin_amdgcn_ballot_w64(bad != 0u) != 0) {   // (wave-uniform, rare)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const uint32_t t1 = swar_ne(sd[d], kKeyT), c1 = swar_ne(sd[d], kKeyC), g1 = swar_ne(sd[d], kKeyG);
+              ccU[d] = t1 + 2u * c1 + 3u * g1 - 0x03030303u;   // (per byte 0..3: no carries)
+            }
+          }
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
         const uint32_t n = K == 1 ? nl : (nl > 8u * (uint32_t)k ? (nl - 8u * (uint32_t)k > 8u ? 8u : nl - 8u * (uint32_t)k) : 0u);
@@ -1120,6 +1160,21 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             qhist_add<3, kHistBase>(wr, mask7, qcol[k][3], jj ? one_hi : one_lo);
           }
         }
+        if constexpr (LUTV) {
+          // counters from the code bytes: T and C through one table lookup each (the selector is the code), "A or C" is the
+          // code's low bit; the spill takes G = events - (A or C) - T.  Codes: one v_dot4 per dword (weights 64 / 16 / 4 / 1).
+          if (count_me) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const uint32_t c = ccU[2 * k + d];
+              acc_t[2 * k + d] += __builtin_amdgcn_perm(0u, lut_is_t, c);
+              acc_c[2 * k + d] += __builtin_amdgcn_perm(0u, lut_is_c, c);
+              acc_g[2 * k + d] += c & 0x01010101u;
+            }
+          }
+          constexpr uint32_t kW = 0x01041040u;
+          own16K[k] = __builtin_amdgcn_udot4(ccU[2 * k + 1], kW, __builtin_amdgcn_udot4(ccU[2 * k], kW, 0u, false) << 8, false);
+        } else
         if (MODE == 0 || MODE == 3) {
           // letter indicators: the adapter scan needs those of the real bytes
           // (feeder lanes and chunk tails must still yield the real codes; window

@@ -432,6 +432,38 @@ def test_every_byte_value_is_defined_and_identical():
                 ob.accumulate_batch(seq, qual, off, kmers=k))
 
 
+@pytest.mark.parametrize("L", [300, 150, 100, 64])
+@pytest.mark.parametrize("alphabet", ["all256", "rare_iupac", "acgtn_mixed_case"])
+def test_base_codes_by_table_lookup_are_exact_on_every_byte(L, alphabet):
+    """The fixed-length adapter kernel (16 positions per lane) takes a base's 2-bit code from bits 3..1 of the byte by
+    table lookup (round 5) and falls back, a wave and a step at a time, to the exact five-bit rule when a byte is met for
+    which the two differ: the other letters of A..T (quack.c:148-150 maps B, D, E, F, R, S ... to A) and, outside the
+    reference's domain, the oracle's `c & 31` rule.  All 256 byte values (every step takes the exact path), ordinary reads
+    with one such byte in ~2000 (most steps take the lookup, some the exact path, inside one launch), and A C G T N in
+    either case (the lookup alone) — adapters spliced in, so that content counters AND first hits are compared."""
+    rng = np.random.default_rng(1000 + L)
+    n = 30001
+    ads = synth.synthetic_adapters()
+    seq, qual = synth.fixed(n, L, seed=L)
+    if alphabet == "all256":
+        seq = rng.integers(0, 256, n * L).astype(np.uint8)
+    elif alphabet == "rare_iupac":
+        odd = np.frombuffer(b"BDEFHIJKLMOPQRSUVWXYbdefhijklmopqrsuvwxy@[`{\x00\xff\x7f0123456789", np.uint8)
+        at = np.flatnonzero(rng.random(n * L) < 1 / 2000)
+        seq = seq.copy()
+        seq[at] = odd[rng.integers(0, len(odd), len(at))]
+    else:
+        seq = np.frombuffer(b"ACGTNacgtn", np.uint8)[rng.integers(0, 10, n * L)]
+    seq = synth.splice_adapters(seq, L, ads, seed=5)
+    if alphabet == "rare_iupac":   # ... and some of them INSIDE an adapter occurrence: the window must stop matching
+        at = np.flatnonzero(rng.random(n * L) < 1 / 5000)
+        seq[at] = np.frombuffer(b"RSBDVWU", np.uint8)[rng.integers(0, 7, len(at))]
+    k = ob.kmers_from_seqs(ads)
+    want = ob.accumulate_batch(seq, qual, read_len=L, kmers=k)
+    assert_same(hip_table(seq, qual, read_len=L, kmers_bits=ob.kmers_to_bitset(k)), want)
+    assert want[0][:, 96].sum() > 100
+
+
 def test_four_level_quality_worst_case_contention():
     rng = np.random.default_rng(9)
     n, L = 40000, 150
