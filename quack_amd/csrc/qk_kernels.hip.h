@@ -242,8 +242,82 @@ constexpr uint32_t kCandWords16 = 16u * kCandCap16 * 4u;
 constexpr uint32_t kFhRing = 2048;      // the smallest ring (what fits beside a 304-position histogram); HistParams::fh_words is the launch's
 constexpr uint32_t kFhRingMax = 16384;  // (round 4: the planner takes the largest power of two the LDS has room for — a fold every
                                         //  fh_words / 2 reads costs every wave a drain of its queue, however empty, and a barrier)
+// WIDE layout (round 5) of the one VALU-bound variant — fixed-length reads, fused adapter scan, 16 positions per lane.  A lane
+// owns a PAIR of chunks, and the u16-pair counters of a pair's byte-b columns (set s) are the two dwords `pair` and `pair + 32`
+// of a 64-dword row; the quality counter of (row q, pair index p, odd chunk o) lives at LDS byte
+//     (p / 32) * 65536 + q * 256 + (p % 32) * 4 + o * 128
+// so the row is BYTE 1 of the address: an address register is a per-lane constant (plane in byte 2, column in byte 0) that serves
+// both chunks of the lane (the odd one through the instruction's offset field), and one SDWA instruction per base —
+//   v_and_b32_sdwa addr, 0x7f, w  dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src1_sel:BYTE_j
+// — extracts the quality byte, masks it and puts it in place (the narrow layout: shift + v_bitop3, two per base and eight address
+// registers; here 36 -> 20 VALU per 16 positions with the rotation, and four registers).  Bank = column as before.  A plane (64
+// columns x 128 rows) is 32 KiB and planes lie 64 KiB apart — bit 15 of an address is part of byte 1 and must stay clear —, which
+// leaves two 32 KiB gaps: the 9-mer filter sits in the first (a probe's address is key field + 32768, the constant goes into the
+// instruction's offset field), the candidate queues, the letter / length / kmer rows and the bucket table in the second.  The
+// first-hit ring takes the pairs of the last plane that no counter uses (128 rows x 32 or 16 words) when it fits there.
+constexpr uint32_t kWidePlaneStride = 16384u;       // dwords between planes (64 KiB)
+constexpr uint32_t kWideFilterOff = 8192u;          // dwords: [32 KiB, 64 KiB)
+constexpr uint32_t kWideRestOff = 24576u;           // dwords: [96 KiB, 128 KiB) queue | letter rows | misc | buckets
+constexpr uint32_t kWideTopOff = 32768u;            // dwords: from 128 KiB on (fewer than three planes): buckets | ring
+__host__ __device__ constexpr uint32_t qhist_index_wide(uint32_t row, uint32_t pair, uint32_t odd) {
+  return (pair >> 5) * kWidePlaneStride + row * 64u + (pair & 31u) + odd * 32u;
+}
+inline __host__ __device__ uint32_t wide_planes(uint32_t cols) { return (cols + 63u) / 64u; }   // cols = 4 R CH = two per pair
+// words of a first-hit ring that fit into the unused pairs of the last plane: W = 32 or 16 words per row (the last W / 2
+// pairs): word i lives in row i / W, at dword 32 - W / 2 + (i % W) % (W / 2) + 32 * ((i % W) / (W / 2))
+inline __host__ __device__ uint32_t wide_spare_ring(uint32_t cols) {
+  const uint32_t free_pairs = wide_planes(cols) * 32u - cols / 2u;
+  return free_pairs >= 16u ? 4096u : free_pairs >= 8u ? 2048u : 0u;
+}
+// Where the bucket table and the first-hit ring of a wide launch go (host and kernel compute the same): the bucket table behind
+// the small rows in the second gap if it fits there, else behind the last plane's slot; the ring in the last plane's unused pairs
+// if it fits there, else behind the last plane's slot (fewer than three planes), else in the second gap.
+struct WidePlan {
+  uint32_t planes;
+  uint32_t bucket_off;   // dwords from LDS byte 0
+  uint32_t ring_off;     // dwords from LDS byte 0; 0: in the unused pairs of the last plane
+  uint32_t bytes;        // of dynamic LDS to ask for; 0: the shape does not fit
+};
+inline __host__ __device__ WidePlan wide_plan(uint32_t ch, uint32_t replicas, uint32_t bucket_log2, uint32_t fh_words) {
+  WidePlan w{};
+  const uint32_t cols = 4u * replicas * ch;
+  w.planes = wide_planes(cols);
+  if (w.planes > 3u) return w;
+  uint32_t gap_at = kWideRestOff + kCandWords16 + 6u * 8u * ch + 4u;   // queue | [4][TP] letters | length | kmer | misc
+  const uint32_t gap_end = kWideTopOff;
+  uint32_t top_at = kWideTopOff;
+  const uint32_t top_end = w.planes == 3u ? kWideTopOff : kWideTopOff + 8192u;   // (three planes: the last one lives there)
+  if (gap_at > gap_end) return w;
+  const uint32_t bw = bucket_log2 ? (4u << bucket_log2) : 0u;
+  if (bw <= gap_end - gap_at) {
+    w.bucket_off = gap_at;
+    gap_at += bw;
+  } else if (bw <= top_end - top_at) {
+    w.bucket_off = top_at;
+    top_at += bw;
+  } else {
+    return w;
+  }
+  if (fh_words <= wide_spare_ring(cols)) {
+    w.ring_off = 0;
+  } else if (fh_words <= top_end - top_at) {
+    w.ring_off = top_at;
+    top_at += fh_words;
+  } else if (fh_words <= gap_end - gap_at) {
+    w.ring_off = gap_at;
+    gap_at += fh_words;
+  } else {
+    return w;
+  }
+  w.bytes = (w.planes == 3u ? kWideTopOff + 8192u : top_at) * 4u;
+  return w;
+}
 inline size_t hist_lds_bytes(uint32_t ch, uint32_t replicas, bool adapt = false, uint32_t bucket_log2 = 0, bool ragged = false,
                              uint32_t stage_reads = kStageReads, bool w16 = false, uint32_t fh_words = kFhRing) {
+  if (adapt && w16 && !ragged) {   // the wide variant (hist_body: WIDE)
+    const size_t b = wide_plan(ch, replicas, bucket_log2, fh_words).bytes;
+    return b ? b : (size_t)1 << 30;   // (does not fit: larger than any LDS)
+  }
   return ((size_t)kQRows * hist_row_dwords(ch, replicas) + (adapt ? 6u : 5u) * 8u * ch + 4u + (adapt ? kFusedFilterWords + (w16 ? kCandWords16 : kCandWords) : 0u)) * sizeof(uint32_t) +
          (adapt && bucket_log2 ? ((size_t)16 << bucket_log2) : 0) + (ragged ? (size_t)stage_reads * (adapt ? 12 : 8) : 0) +
          (adapt && !ragged ? (size_t)fh_words * 4 : 0);   // fixed-length batches: the first-hit ring (where a ragged batch stages its reads)
@@ -336,6 +410,30 @@ __device__ __forceinline__ void qhist_add(uint32_t w, uint32_t mask7, uint32_t q
 #endif
 }
 
+// wide layout (qhist_index_wide): the quality row is byte 1 of the counter's address, so ONE instruction takes byte J of the
+// quality dword, masks it to 7 bits and puts it into the lane's address register, whose other bytes (plane, column) stay
+template <int J, uint32_t OFF>
+__device__ __forceinline__ void qhist_add_wide(uint32_t w, uint32_t m7f, uint32_t &addr, uint32_t val) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(J >= 0 && J < 4, "byte of a dword");
+#ifdef QK_WIDE_NOSDWA   /* experiment: the same layout, the address by plain instructions */
+  {
+    const uint32_t a2 = (((w >> (8 * J)) & 0x7Fu) << 8) | (addr & 0xFFFF00FFu);
+    __hip_atomic_fetch_add((lds_u32 *)a2 + OFF / 4u, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    (void)m7f;
+    return;
+  }
+#endif
+  if constexpr (J == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0" : "+v"(addr) : "v"(m7f), "v"(w));
+  if constexpr (J == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_1" : "+v"(addr) : "v"(m7f), "v"(w));
+  if constexpr (J == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2" : "+v"(addr) : "v"(m7f), "v"(w));
+  if constexpr (J == 3) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3" : "+v"(addr) : "v"(m7f), "v"(w));
+  __hip_atomic_fetch_add((lds_u32 *)addr + OFF / 4u, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  (void)w; (void)m7f; (void)addr; (void)val;
+#endif
+}
+
 // value of the same register in lane-1 (v_mov_b32_dpp wave_shr:1); lane 0 gets 0
 __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
@@ -378,7 +476,11 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 // (the long-read build — ragged, W16, no adapter scan — is held to 120 VGPRs: four of its waves then leave 32 registers of
 // a SIMD free, which is what the waves of the NEXT batch's reach pre-pass (12-16 VGPRs, 2 KiB of LDS) need to run beside it
 // on the side stream instead of waiting for a workgroup to retire)
-template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false, bool NP = false>
+// ONE (round 5): the launch has one position tile and no work queue — block b owns read slice b, nothing else is compiled in.
+// The VALU-bound variant (fixed length + adapter scan + 16 positions per lane) runs at the register file's limit (128 VGPRs for
+// four waves per SIMD); with the three work-loop forms inlined side by side the one-tile form's step loop spilled its counter
+// addresses to scratch (s_waitcnt vmcnt(0) in front of every LDS atomic: the kernel ran at half speed).
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false, bool NP = false, bool ONE = false>
 __device__ __forceinline__ void hist_body(const HistParams &p) {
   static_assert(!NP || SV, "neutral pads are a property of strided batches");
   static_assert(!SV || (FIXED && AL), "strided batches are a variant of the dword-aligned fixed-length path");
@@ -388,27 +490,34 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   using LoadT = typename load_reg<W16>::type;
   constexpr uint32_t kCandWordsT = W16 ? kCandWords16 : kCandWords;
   extern __shared__ uint32_t lds_raw[];
+  // the wide LDS layout of the VALU-bound variant (see qhist_index_wide): counter planes 64 KiB apart, the filter and the
+  // small rows in the gaps
+  constexpr bool WIDE = W16 && ADAPT && FIXED && !SV && MODE == 0;
   // ADAPT: the window filter sits first, so that the probes' LDS addresses are
   // "field + constant" (no per-probe add of a layout-dependent base)
-  uint32_t *lds = lds_raw + (ADAPT ? kFusedFilterWords + kCandWordsT : 0u);
+  uint32_t *lds = lds_raw + ((ADAPT && !WIDE) ? kFusedFilterWords + kCandWordsT : 0u);
   const uint32_t tid = threadIdx.x;
   const uint32_t CH = p.ch;
   const uint32_t RD = p.row_dwords;
   const uint32_t TP = 8u * CH;  // == p.tile_pos
-  const uint32_t hist_words = kQRows * RD;
-  uint32_t *lds_base = lds + hist_words;  // [4][TP]
+  const uint32_t wide_cols = 4u * p.replicas * CH, wide_np = wide_planes(wide_cols);
+  const uint32_t hist_words = kQRows * RD;   // (narrow layout)
+  uint32_t *lds_base = WIDE ? lds_raw + kWideRestOff + kCandWords16 : lds + hist_words;  // [4][TP]
   uint32_t *lds_len = lds_base + 4u * TP;
   uint32_t *lds_kmer = lds_len + TP;      // ADAPT: kmer_count of the tile (count_in_kernel)
   uint32_t *lds_misc = lds_kmer + (ADAPT ? TP : 0u);      // [0] reads longer than 10, [1] next item
-  uint32_t *lds_filter = lds_raw;         // ADAPT only
+  uint32_t *lds_filter = WIDE ? lds_raw + kWideFilterOff : lds_raw;         // ADAPT only
   const uint8_t *filt8 = reinterpret_cast<const uint8_t *>(lds_raw);   // == LDS byte 0, see lds_abs_u8
   (void)filt8;
   // ragged batches: descriptors {start - slice base, length [| index << 16]} of
   // the reads of the current pass that reach this tile, compacted
   // (the filter, hist words, 5*TP and 4 are all multiples of 4 dwords: 16-byte aligned)
-  uint4 *lds_buckets = reinterpret_cast<uint4 *>(lds_misc + 4u);
+  // (wide: wide_plan says where the bucket table and the ring go)
+  const WidePlan wplan = WIDE ? wide_plan(CH, p.replicas, p.bucket_log2, p.fh_words) : WidePlan{};
+  uint4 *lds_buckets = reinterpret_cast<uint4 *>(WIDE ? lds_raw + wplan.bucket_off : lds_misc + 4u);
   uint2 *lds_list = reinterpret_cast<uint2 *>(
-      reinterpret_cast<char *>(lds_misc + 4u) + ((ADAPT && p.bucket_log2) ? (16u << p.bucket_log2) : 0u));
+      WIDE ? reinterpret_cast<char *>(lds_raw + wplan.ring_off)
+           : reinterpret_cast<char *>(lds_misc + 4u) + ((ADAPT && p.bucket_log2) ? (16u << p.bucket_log2) : 0u));
   const uint32_t SR = STAGED ? p.stage_reads : kStageReads;
   uint32_t *lds_ridx = reinterpret_cast<uint32_t *>(lds_list + SR);   // ADAPT: index of a staged read within its pass
   uint32_t *lds_fh = reinterpret_cast<uint32_t *>(lds_list);          // ADAPT, FIXED: the first-hit ring (HistParams::fh_words words)
@@ -467,6 +576,16 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   // a step of more reads than half the ring — reads of a chunk or two — keeps the global words)
   const uint32_t FHW = (ADAPT && FIXED) ? p.fh_words : kFhRing, FHM = FHW - 1u;
   const bool fh_ring = ADAPT && FIXED && p.count_in_kernel != 0 && RW * (uint32_t)U * GRP <= FHW / 2u;
+  // wide layout: the ring lives in the columns of the last counter plane that no counter uses, fh_w (32 or 16) words per row
+  const uint32_t fh_w = (WIDE && wplan.ring_off == 0u) ? (wide_spare_ring(wide_cols) >> 7) : 0u;
+  const uint32_t fh_sh = fh_w == 32u ? 5u : 4u;
+  auto fh_at = [&](uint32_t i) -> uint32_t * {   // word i (< FHW) of the ring
+    if (WIDE && fh_w) {
+      const uint32_t w = i & (fh_w - 1u), half = fh_w >> 1;   // the row's free pairs: dwords [32 - half, 32) and the same + 32
+      return lds_raw + (wide_np - 1u) * kWidePlaneStride + ((i >> fh_sh) << 6) + (32u - half) + (w & (half - 1u)) + ((w >> (fh_sh - 1u)) << 5);
+    }
+    return lds_fh + i;
+  };
   // rows between two folds of the ring: whole steps, their reads at most half the ring
   const uint32_t fh_group = fh_ring ? (FHW / 2u / GRP) / (RW * (uint32_t)U) * (RW * (uint32_t)U) : 0u;
   constexpr bool kScalarLoop = W16 && ADAPT && FIXED;   // see the step loop
@@ -488,15 +607,20 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
 #pragma unroll
   for (int k = 0; k < K; ++k)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qcol[k][i] = qhist_index(0u, ((kset + i) % (4u * R)) * CH + lds_col(chk[k])) * 4u;
-  constexpr uint32_t kHistBase = ADAPT ? (kFusedFilterWords + kCandWordsT) * 4u : 0u;   // == (char*)lds - LDS byte 0
-  uint32_t mask7;   // 127 << 7 in a VGPR (an SGPR or literal operand would put v_bitop3 in the slow class)
-  asm("v_mov_b32 %0, 0x3f80" : "=v"(mask7));
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t set = (kset + i) % (4u * R);
+      // (wide: one register per set serves both chunks — the odd one 128 bytes further on —, byte 1, the row, is rewritten for every base)
+      qcol[k][i] = (WIDE ? qhist_index_wide(0u, set * (CH / 2u) + chl, 0u) : qhist_index(0u, set * CH + lds_col(chk[k]))) * 4u;
+    }
+  constexpr uint32_t kHistBase = (ADAPT && !WIDE) ? (kFusedFilterWords + kCandWordsT) * 4u : 0u;   // == (char*)lds - LDS byte 0
+  uint32_t mask7;   // 127 << 7 in a VGPR (an SGPR or literal operand would put v_bitop3 in the slow class); wide: 127
+  if constexpr (WIDE) asm("v_mov_b32 %0, 0x7f" : "=v"(mask7));
+  else asm("v_mov_b32 %0, 0x3f80" : "=v"(mask7));
   const uint32_t one_lo = 1u, one_hi = 65536u;
 
   // ADAPT: this wave's candidate queue (see kCandCap) and its fill (wave-uniform)
   uint2 *cand_q = reinterpret_cast<uint2 *>(lds_raw + kFusedFilterWords) + (tid >> 6) * kCandCap;
-  uint4 *cand_q16 = reinterpret_cast<uint4 *>(lds_raw + kFusedFilterWords) + (tid >> 6) * kCandCap16;   // W16: 16-byte entries
+  uint4 *cand_q16 = reinterpret_cast<uint4 *>(lds_raw + (WIDE ? kWideRestOff : kFusedFilterWords)) + (tid >> 6) * kCandCap16;   // W16: 16-byte entries
   uint32_t cand_n = 0;
   uint32_t n_gt10 = 0;        // reads longer than 10 (kmers==NULL path, quack.c:215)
   uint32_t fixed_reads = 0;   // FIXED, tile 0: reads seen since the last flush
@@ -570,6 +694,11 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
 #if defined(QK_ABL) && (QK_ABL & 2048)   /* experiment: ... without clearing the LDS image */
     return;
 #endif
+    if constexpr (WIDE) {   // the planes (with the ring's columns: process() sets those) and the letter / length / kmer rows + misc[0]
+      for (uint32_t pl = 0; pl < wide_np; ++pl)
+        for (uint32_t i = tid; i < 128u * 64u; i += T) lds_raw[pl * kWidePlaneStride + i] = 0;
+      for (uint32_t i = tid; i < 6u * TP + 1u; i += T) lds_base[i] = 0;
+    } else
     for (uint32_t i = tid; i < hist_words + (ADAPT ? 6u : 5u) * TP + 1u; i += T) lds[i] = 0;
   };
 
@@ -600,7 +729,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           const uint32_t col = pp + gi * GS;
           const uint32_t c8 = col >> 3, j = col & 7u;
           for (uint32_t rep = 0; rep < R; ++rep) {
-            const uint32_t w = lds[qhist_index(row, (rep * 4u + (j & 3u)) * CH + lds_col(c8))];
+            const uint32_t hs = rep * 4u + (j & 3u);   // the set
+            const uint32_t w = WIDE ? lds_raw[qhist_index_wide(row, hs * (CH / 2u) + (c8 >> 1), c8 & 1u)] : lds[qhist_index(row, hs * CH + lds_col(c8))];
             c += (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
           }
         }
@@ -691,7 +821,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     // 45 us of a 1.5 ms step on 10M x 300.  Reset here, count below, both with device-coherent
     // accesses: the atomicMin of the drain happens at the memory side.
     if (fh_ring) {
-      for (uint32_t i = tid; i < FHW; i += T) lds_fh[i] = kNoHit;
+      for (uint32_t i = tid; i < FHW; i += T) *fh_at(i) = kNoHit;
       fh_folded = 0;
       fh_next = fh_group;
       __syncthreads();
@@ -760,11 +890,11 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     auto fold_first_hits = [&](uint32_t upto) {
       // (grouped rows: the ring holds one word per READ, row * group + the read's place in the row)
       for (uint32_t rel = fh_folded * GRP + tid; rel < upto * GRP; rel += T) {
-        const uint32_t v = lds_fh[rel & FHM];
+        const uint32_t v = *fh_at(rel & FHM);
         if (v == kNoHit) continue;
         const uint32_t len = SV ? p.lengths[(size_t)r_begin + rel] : p.read_len;
         if (v + 1u < len && v + 1u < TP) lds_add(lds_kmer, 4u * (v + 1u), 1u);
-        lds_fh[rel & FHM] = kNoHit;
+        *fh_at(rel & FHM) = kNoHit;
       }
       fh_folded = upto;
     };
@@ -988,7 +1118,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             rd = ring;           // (what tells two reads apart below)
             if (g0 + 1u < GRP && pos0 + NW > GS) {
               const uint32_t j1 = first_in_table(hits & window_mask((int32_t)pos0 - (int32_t)GS, len));
-              if (j1 < NW) __hip_atomic_fetch_min(&lds_fh[(ring + 1u) & FHM], pos0 + j1 - GS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (j1 < NW) __hip_atomic_fetch_min(fh_at((ring + 1u) & FHM), pos0 + j1 - GS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
           // An adapter covers several chunks of its read, and their entries sit next to each other in
@@ -1001,7 +1131,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           if (found != kNoHit && !covered) keep ^= found + rd;
 #else
           if (found != kNoHit && !covered) {
-            if (fh_ring) __hip_atomic_fetch_min(&lds_fh[ring & FHM], found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (fh_ring) __hip_atomic_fetch_min(fh_at(ring & FHM), found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else atomicMin(&p.first_hit[rd], found);
           }
 #endif
@@ -1239,7 +1369,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
               for (int m = 0; m < 4; ++m) bytU[u][k][m] = 0u;
               if (QK_ABL & 2) keep ^= plo;   /* (the codes stay alive) */
 #else
-              for (int m = 0; m < 4; ++m) bytU[u][k][m] = lds_abs_u32((plo >> (2 * (7 - 2 * m) + 3)) & ((1u << (kFusedFilterLog2 - 3)) - 4u));
+              for (int m = 0; m < 4; ++m)   // (wide: the filter sits at byte 32768 — the constant goes into the instruction's offset field)
+                bytU[u][k][m] = lds_abs_u32(((plo >> (2 * (7 - 2 * m) + 3)) & ((1u << (kFusedFilterLog2 - 3)) - 4u)) + (WIDE ? kWideFilterOff * 4u : 0u));
 #endif
             }
           }
@@ -1271,6 +1402,20 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
               keep ^= ((wr & 0x7Fu) << 7 | qcol[k][0]) ^ (((wr >> 1) & mask7) | qcol[k][1]) ^ (((wr >> 9) & mask7) | qcol[k][2]) ^ (((wr >> 17) & mask7) | qcol[k][3]);
               continue;
 #endif
+              if constexpr (WIDE) {   // (the address registers of the lane's first chunk; the second chunk's counters are 32 dwords on)
+                if (k == 0) {
+                  qhist_add_wide<0, 0u>(wr, mask7, qcol[0][0], jj ? one_hi : one_lo);
+                  qhist_add_wide<1, 0u>(wr, mask7, qcol[0][1], jj ? one_hi : one_lo);
+                  qhist_add_wide<2, 0u>(wr, mask7, qcol[0][2], jj ? one_hi : one_lo);
+                  qhist_add_wide<3, 0u>(wr, mask7, qcol[0][3], jj ? one_hi : one_lo);
+                } else {
+                  qhist_add_wide<0, 128u>(wr, mask7, qcol[0][0], jj ? one_hi : one_lo);
+                  qhist_add_wide<1, 128u>(wr, mask7, qcol[0][1], jj ? one_hi : one_lo);
+                  qhist_add_wide<2, 128u>(wr, mask7, qcol[0][2], jj ? one_hi : one_lo);
+                  qhist_add_wide<3, 128u>(wr, mask7, qcol[0][3], jj ? one_hi : one_lo);
+                }
+                continue;
+              }
               qhist_add<0, kHistBase>(wr, mask7, qcol[k][0], jj ? one_hi : one_lo);
               qhist_add<1, kHistBase>(wr, mask7, qcol[k][1], jj ? one_hi : one_lo);
               qhist_add<2, kHistBase>(wr, mask7, qcol[k][2], jj ? one_hi : one_lo);
@@ -1457,6 +1602,9 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     }
     reads_in_tile += process(tile, rb, re);
   };
+  if constexpr (ONE) {
+    if (blockIdx.x < p.n_slices) run_item(0, (uint64_t)blockIdx.x * p.reads_per_slice, (uint64_t)(blockIdx.x + 1u) * p.reads_per_slice);
+  } else
   if (p.static_split) {
     // Several tiles, work known: the read-tiles (tile 0's reads, then tile 1's, ...) are cut into
     // gridDim.x equal shares; a share is a contiguous read range in one tile, sometimes the tail of
@@ -1564,11 +1712,11 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   if (cur_tile != 0xFFFFFFFFu) flush(cur_tile);
 }
 
-template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false, bool NP = false>
+template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false, bool NP = false, bool ONE = false>
 // (strided builds without the adapter scan are held to 64 VGPRs for two workgroups per CU — also the one without tail masks, NP:
 // measured with one workgroup 0.5975 ms per 10M trimmed 150 bp reads, with two 0.5178; the masked build 0.5300)
 __global__ __launch_bounds__(T, (SV && !ADAPT) ? (T / 256) * 2 : QK_MIN_WAVES_PER_SIMD) void hist_kernel(const HistParams p) {
-  hist_body<T, U, FIXED, MODE, ADAPT, PD, AL, SV, W16, NP>(p);
+  hist_body<T, U, FIXED, MODE, ADAPT, PD, AL, SV, W16, NP, ONE>(p);
 }
 
 // (A build of the long-read variant held to 120 VGPRs — four of its waves then leave 32 registers of a SIMD free, room for

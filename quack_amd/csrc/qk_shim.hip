@@ -274,8 +274,7 @@ uint32_t single_tile_cap(const qk_accum *a, bool ragged, bool w16) {
 // when nothing is gained.  Only under the planner's own geometry, with the first hits in the LDS ring.
 uint32_t choose_group(const qk_accum *a, uint64_t n_reads, uint32_t read_len, uint32_t stride, bool base_aligned4, uint32_t row_cap = 0) {
   if (!a->adapters || getenv("QUACK_HIP_UNFUSED_ADAPTERS") || getenv("QUACK_HIP_NO_GROUP") || getenv("QUACK_HIP_NO_W16") ||
-      getenv("QUACK_HIP_NO_ALIGN4") || getenv("QUACK_HIP_SEPARATE_COUNT") || getenv("QUACK_HIP_ADAPT_PD") || getenv("QUACK_HIP_ADAPT_U") ||
-      getenv("QUACK_HIP_W16_U") || getenv("QUACK_HIP_W16_PD"))
+      getenv("QUACK_HIP_NO_ALIGN4") || getenv("QUACK_HIP_SEPARATE_COUNT") || getenv("QUACK_HIP_ADAPT_PD") || getenv("QUACK_HIP_ADAPT_U"))
     return 1;
   if (a->unroll || a->pipe || a->threads != 1024 || a->tile > 0 || a->wgs_per_cu > 0) return 1;
   if ((stride & 3u) || stride < 16u || read_len < 11u || !base_aligned4) return 1;
@@ -371,8 +370,8 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
     // read hold the next read's bytes and are never flushed, as before), one read per lane and step with the
     // next step's loads in flight — the same bytes in flight as two reads of 8 positions
     tile_pos = (uint32_t)round_up(tile_pos, 16);
-    pl->unroll = env_int("QUACK_HIP_W16_U", 1);
-    pl->pipe = env_int("QUACK_HIP_W16_PD", 2);
+    pl->unroll = 1;
+    pl->pipe = 2;
   }
   pl->w16 = w16;
   pl->n_tiles = n_tiles;
@@ -499,8 +498,10 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
   if (w16) {
     // 16 positions per lane: built for the step shapes the planner (or QUACK_HIP_W16_U / _PD) asks for
     if (aligned && mode == 0 && !strided) {
-      if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 2)) {
-        if (fixed) k = adapt ? qk::hist_kernel<T, U, true, 0, true, PD, true, false, true> : qk::hist_kernel<T, U, true, 0, false, PD, true, false, true>;
+      if constexpr (T == 1024 && PD == 2 && U == 1) {
+        const bool one = hp.n_tiles == 1 && !hp.queue && !hp.static_split;
+        if (fixed && adapt) k = one ? qk::hist_kernel<T, U, true, 0, true, PD, true, false, true, false, true> : qk::hist_kernel<T, U, true, 0, true, PD, true, false, true>;
+        else if (fixed) k = qk::hist_kernel<T, U, true, 0, false, PD, true, false, true>;
         else k = adapt ? qk::hist_kernel<T, U, false, 0, true, PD, true, false, true> : qk::hist_kernel<T, U, false, 0, false, PD, true, false, true>;
       }
     }

@@ -285,7 +285,7 @@ def test_sixteen_positions_per_lane_on_and_off(monkeypatch):
     seq, qual = synth.fixed(30000, 300, seed=5)
     seq = synth.splice_adapters(seq, 300, ads, seed=6)
     want = ob.accumulate_batch(seq, qual, read_len=300, kmers=k)
-    for env in ({}, {"QUACK_HIP_NO_W16": "1"}, {"QUACK_HIP_W16_U": "2"}):
+    for env in ({}, {"QUACK_HIP_NO_W16": "1"}):
         for kk, v in env.items():
             monkeypatch.setenv(kk, v)
         assert_same(hip_table(seq, qual, read_len=300, kmers_bits=bits), want)

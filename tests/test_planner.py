@@ -89,7 +89,7 @@ def test_rows_of_several_reads():
             assert p["lds"] <= 160 * 1024, (read_len, blog, p)
             assert p["row"] == (p["group"] - 1) * stride + read_len
             if p["group"] > 1:
-                assert p["w16"] == 1 and p["tile_pos"] >= p["row"] and p["tile_pos"] % 16 == 0 and p["tile_pos"] <= 320, (read_len, blog, p)
+                assert p["w16"] == 1 and p["tile_pos"] >= p["row"] and p["tile_pos"] % 16 == 0 and p["tile_pos"] <= 352, (read_len, blog, p)
                 assert p["rw"] * p["unroll"] * p["group"] <= 1024, (read_len, blog, p)
                 assert p["bucket_log2"] == blog or blog == 0, (read_len, blog, p)      # never at the price of the exact LDS table
                 lanes1 = -(-read_len // 16) * 16 / read_len

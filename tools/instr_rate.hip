@@ -44,7 +44,15 @@
   X(37, "v_cmp_ne_u32 + nothing", "v_cmp_ne_u32 vcc, %0, %1")                                          \
   X(38, "v_max_u32", "v_max_u32 %0, %0, %1")                                                           \
   X(39, "v_ashrrev_i32 const", "v_ashrrev_i32 %0, 3, %0")                                              \
-  X(40, "v_lshl_add_u32 (shift 0)", "v_lshl_add_u32 %0, %0, 0, %1")
+  X(40, "v_lshl_add_u32 (shift 0)", "v_lshl_add_u32 %0, %0, 0, %1")                                    \
+  X(41, "v_and sdwa BYTE_1 PRESERVE", "v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2") \
+  X(42, "v_and sdwa BYTE_1 PAD", "v_and_b32_sdwa %0, %1, %0 dst_sel:BYTE_1 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2") \
+  X(43, "v_and sdwa WORD_1 PRESERVE", "v_and_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2") \
+  X(44, "v_mov sdwa BYTE_1 PRESERVE", "v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2") \
+  X(45, "v_and sdwa DWORD src BYTE", "v_and_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2") \
+  X(46, "v_msad_u8", "v_msad_u8 %0, %0, %1, %2")                                                       \
+  X(47, "v_bfi_b32", "v_bfi_b32 %0, %1, %0, %2")                                                       \
+  X(48, "v_perm_b32 (0, v, v)", "v_perm_b32 %0, 0, %1, %0")
 
 template <int OP, bool CHAIN>
 __global__ __launch_bounds__(1024) void k(unsigned *out, unsigned seed) {
