@@ -484,7 +484,8 @@ template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bo
 __device__ __forceinline__ void hist_body(const HistParams &p) {
   static_assert(!NP || SV, "neutral pads are a property of strided batches");
   static_assert(!SV || (FIXED && AL), "strided batches are a variant of the dword-aligned fixed-length path");
-  static_assert(!W16 || (AL && !SV && MODE == 0), "16 positions per lane: dword-aligned batches only");
+  static_assert(!W16 || (AL && MODE == 0 && (!SV || (NP && ADAPT && FIXED))),
+                "16 positions per lane: dword-aligned batches; strided ones with neutral pads and the adapter scan only");
   constexpr bool STAGED = !FIXED;   // ragged batches: the read list is staged in LDS pass by pass
   constexpr int K = W16 ? 2 : 1;    // 8-position chunks per lane
   using LoadT = typename load_reg<W16>::type;
@@ -492,7 +493,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   extern __shared__ uint32_t lds_raw[];
   // the wide LDS layout of the VALU-bound variant (see qhist_index_wide): counter planes 64 KiB apart, the filter and the
   // small rows in the gaps
-  constexpr bool WIDE = W16 && ADAPT && FIXED && !SV && MODE == 0;
+  constexpr bool WIDE = W16 && ADAPT && FIXED && MODE == 0;
   // ADAPT: the window filter sits first, so that the probes' LDS addresses are
   // "field + constant" (no per-probe add of a layout-dependent base)
   uint32_t *lds = lds_raw + ((ADAPT && !WIDE) ? kFusedFilterWords + kCandWordsT : 0u);
@@ -524,7 +525,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
 
   const uint64_t TL = p.table_len;
   // grouped rows (HistParams::group): built into the one variant the planner uses them with
-  constexpr bool GROUPS = W16 && ADAPT && FIXED && !SV;
+  constexpr bool GROUPS = W16 && ADAPT && FIXED;
   const uint32_t GRP = GROUPS ? p.group : 1u;
   const uint32_t GS = GROUPS ? p.gstride : 0u;
   const uint32_t row_len = FIXED ? (GRP - 1u) * GS + p.read_len : 0u;   // positions of a row that hold reads (SV: the stride)
@@ -645,7 +646,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   constexpr bool FAST_FIXED = FIXED && (!SV || NP);   // no tail masks
   // LUTV (round 5; the fused adapter scan on fixed-length reads, 16 positions per lane — the VALU-bound variant): base codes by
   // table lookup (v_perm_b32) instead of three SWAR indicators per dword, see consume
-  constexpr bool LUTV = W16 && ADAPT && FIXED && !SV && MODE == 0;
+  constexpr bool LUTV = W16 && ADAPT && FIXED && MODE == 0;
   // code table, selector (byte >> 1) & 7: A 000 -> 3, C 001 -> 1, T 010 -> 2, G 011 -> 0, 100 .. 111 (H-O, X-_, N) -> 3
   constexpr uint32_t lut_cc_lo = 0x00020103u, lut_cc_hi = 0x03030303u;
   // the five-bit key (byte & 31) the classes 001 / 010 / 011 must have for that code to be quack.c:150's: C = 3, T = 20, G = 7
@@ -655,6 +656,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   constexpr bool UNIFORM = FIXED && !SV;              // every read one length: lengths in closed form
   uint32_t events = 0, steps_v = 0;
   uint32_t fixed_mask = 0;   // FIXED: which of the lane's 8K positions are bases of a read (the same for every row): bit i = position cpos + i
+  // strided batches, 16 positions per lane (round 5): the read of a row whose length this lane loads with its bytes — the one that
+  // STARTS in the lane's positions (owns_start: the lane counts that read's length, quack.c:219), else the one its first position lies in
+  uint32_t len_g = 0;
+  bool owns_start = false, straddles = false;   // straddles: the lane's first position belongs to the read BEFORE the one that starts in it
 
   auto spill = [&]() {
 #pragma unroll
@@ -857,8 +862,17 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       fixed_mask = 0u;
       uint32_t g, pos;
       col_split(cpos, g, pos);
+      len_g = g < GRP ? g : GRP - 1u;
+      owns_start = false;
+      straddles = false;
+      const uint32_t g_first = g;
       for (uint32_t i = 0; i < 8u * K; ++i) {
         if (lane_on && cpos + i < row_len && g < GRP && pos < p.read_len) fixed_mask |= 1u << i;
+        if (lane_on && pos == 0u && g < GRP && cpos + i < row_len) {   // a read of the row starts in this lane's positions (one at most: a stride is >= 16)
+          owns_start = true;
+          len_g = g;
+          straddles = g != g_first;
+        }
         ++pos;
         if (GROUPS && GRP > 1u && pos == GS) {
           pos = 0u;
@@ -892,8 +906,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       for (uint32_t rel = fh_folded * GRP + tid; rel < upto * GRP; rel += T) {
         const uint32_t v = *fh_at(rel & FHM);
         if (v == kNoHit) continue;
-        const uint32_t len = SV ? p.lengths[(size_t)r_begin + rel] : p.read_len;
-        if (v + 1u < len && v + 1u < TP) lds_add(lds_kmer, 4u * (v + 1u), 1u);
+        if (v + 1u < TP) lds_add(lds_kmer, 4u * (v + 1u), 1u);   // (the drain only records hits that count: v + 1 < length)
         *fh_at(rel & FHM) = kNoHit;
       }
       fh_folded = upto;
@@ -986,6 +999,11 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       uint32_t fixed_off0[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) fixed_off0[u] = FIXED ? ((uint32_t)u * RW + ri) * p.stride + cposp : 0u;
+      // strided: lengths[] of the slice's reads, and the lane's place in a step's share of it
+      const uint32_t *lrow = SV ? p.lengths + (size_t)r_begin * GRP : nullptr;
+      uint32_t len_idx0[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) len_idx0[u] = ((uint32_t)u * RW + (ri < RW ? ri : 0u)) * GRP + len_g;
       auto issue = [&](uint32_t it, LoadT (&q)[U], LoadT (&s)[U], uint32_t (&nv)[U], uint32_t (&sk)[U],
                        uint32_t (&rl)[U]) __attribute__((always_inline)) {
         const uint32_t it_bytes = FIXED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)it) * p.stride : 0u;
@@ -1010,7 +1028,15 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           nv[u] = lane_on ? n_raw : 0u;
           // strided: the read's own length, in flight together with its bytes (consume turns it into n)
           // (NP: only the lane that counts the length needs it; loading it in that lane alone was measured: 0.5082 / 0.5091 ms)
-          if (SV) nv[u] = in_list ? p.lengths[(size_t)r_begin + rel] : 0u;
+          // (a 32-bit index from the slice's own, wave-uniform base: the step's part by the scalar unit, the lane's part a constant —
+          //  64-bit index arithmetic here was two quarter-rate v_mad_u64_u32 per lane and step; a row that is not in the list loads
+          //  word 0 and is told apart in consume)
+          // (8 positions per lane — the builds of rounds 2-4, one of them held to 64 VGPRs — keep their load under the exec mask: the
+          //  unconditional form measured 8 % slower there, 0.512 -> 0.553 ms per 10M trimmed reads, for no reason the listing shows)
+          if (SV) {
+            if constexpr (W16) nv[u] = lrow[in_list ? (uint32_t)__builtin_amdgcn_readfirstlane((int)it) * GRP + len_idx0[u] : 0u];
+            else nv[u] = in_list ? p.lengths[(size_t)r_begin + rel] : 0u;
+          }
           off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
           sk[u] = AL ? 0u : (off & 3u);
           off &= (AL && !FIXED) ? (W16 ? ~15u : ~7u) : ~3u;
@@ -1053,9 +1079,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       auto drain_candidates = [&]() {
         constexpr uint32_t NW = 8u * K;                 // windows per entry
         for (uint32_t i = lane_id; i < ((cand_n + 63u) & ~63u); i += 64u) {   // whole waves: bpermute below
-          uint32_t src, rel, hits, s_lo, s_hi;
+          uint32_t src, rel, hits, s_lo, s_hi, ez = 0;
           if constexpr (W16) {
             const uint4 e = cand_q16[i < cand_n ? i : 0u];
+            ez = e.z;
             src = (e.z >> 16) & 63u;
             rel = e.w;
             // eight probe bits -> sixteen windows: probe i passed = windows 2i (the 9-mer is its suffix) and 2i + 1 (its prefix)
@@ -1078,16 +1105,17 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           uint32_t len, rd;
           if (FIXED) {
             rd = (uint32_t)r_begin + rel;
-            len = SV ? p.lengths[rd] : p.read_len;
+            len = (SV && !GROUPS) ? lrow[rel] : p.read_len;   // (strided rows of several reads: per read, below)
           } else {
             len = lds_list[rel].y;
             rd = lds_ridx[rel];
           }
           hits = i < cand_n ? hits : 0u;
-          // only windows that end inside the read, at e >= 9 (quack.c:206-213): those of the lane's windows j whose
-          // position base + j lies in [9, ln)
+          // only windows that end inside the read, at e >= 9 (quack.c:206-213), and BEFORE its last base: those of the lane's
+          // windows j whose position base + j lies in [9, ln - 1).  (A first hit that ends on the last base is not counted —
+          // quack.c:215, i == l — and nothing can follow it, so leaving it out changes no count and the fold needs no length.)
           auto window_mask = [&](int32_t base, uint32_t ln) -> uint32_t {
-            int32_t lo = 9 - base, hi = (int32_t)ln - base;
+            int32_t lo = 9 - base, hi = (int32_t)ln - 1 - base;
             lo = lo < 0 ? 0 : lo;
             hi = hi > (int32_t)NW ? (int32_t)NW : hi;
             return hi > lo ? (((1u << (uint32_t)(hi - lo)) - 1u) << (uint32_t)lo) : 0u;
@@ -1110,6 +1138,13 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           // stride, to read g0 + 1 from its position 0 on (a stride is at least 16 positions: two reads at most)
           uint32_t g0, pos0;
           col_split(cp, g0, pos0);
+          uint32_t elen = 0;
+          bool estr = false;
+          if constexpr (SV && GROUPS) {   // (W16: the entry carries a length, see the push)
+            elen = ez & 0x7FFFu;
+            estr = (ez & 0x8000u) != 0;
+            len = estr ? lrow[rel * GRP + (g0 < GRP ? g0 : GRP - 1u)] : elen;
+          }
           const uint32_t j0 = first_in_table(hits & window_mask((int32_t)pos0, len));
           const uint32_t found = j0 < NW ? pos0 + j0 : kNoHit;
           uint32_t ring = rel;   // the read's word in the first-hit ring
@@ -1117,7 +1152,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             ring = rel * GRP + g0;
             rd = ring;           // (what tells two reads apart below)
             if (g0 + 1u < GRP && pos0 + NW > GS) {
-              const uint32_t j1 = first_in_table(hits & window_mask((int32_t)pos0 - (int32_t)GS, len));
+              const uint32_t len1 = SV ? (estr ? elen : 0u) : len;   // (a read that starts in the lane: the entry holds ITS length)
+              const uint32_t j1 = first_in_table(hits & window_mask((int32_t)pos0 - (int32_t)GS, len1));
               if (j1 < NW) __hip_atomic_fetch_min(fh_at((ring + 1u) & FHM), pos0 + j1 - GS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
@@ -1178,15 +1214,20 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         // bytes past the end of the read -> 0xFF: quality row 127 is discarded
         // at flush time, and 0xFF & 31 matches none of T/C/G.
         uint32_t nl = nv[u];     // valid bytes of the lane's K chunks together
+        uint32_t lenv = 0;       // SV: the length that arrived with the bytes (0: the row is not in the list)
         if (SV) {   // nv[u] is the length of the read
-          nl = (lane_on && nv[u] > cpos) ? nv[u] - cpos : 0u;
+          const bool row_in = rl[u] < n_list && ri < RW;
+          lenv = (!W16 || row_in) ? nv[u] : 0u;
+          nl = (lane_on && lenv > cpos) ? lenv - cpos : 0u;
           nl = nl > 8u ? 8u : nl;
-          if (NP) nl = (lane_on && nv[u] != 0u) ? 8u : 0u;   // (every byte of an existing read row counts: pads are neutral)
+          if (NP) nl = (lane_on && lenv != 0u) ? 8u : 0u;   // (every byte of an existing read row counts: pads are neutral)
+          // (16 positions per lane: a row may hold several reads, one of them empty — whether the row exists says the list)
+          if (W16) nl = (lane_on && row_in) ? 8u * K : 0u;
           // length_count (quack.c:219) and the kmers==NULL count (quack.c:215) by the lane that owns the read's first
           // chunk: the length is in its register anyway.  (Late round 3; round 2 counted behind the step loop, a pass
           // of its own over lengths[], and gained nothing over the separate kernel: 24 us per 10M reads.)
-          if (!p.lengths_done && lane_on && chl == 0u && nv[u] != 0u) {
-            const uint32_t len = nv[u];
+          if (!p.lengths_done && lane_on && (W16 ? (owns_start && row_in) : chl == 0u) && lenv != 0u) {
+            const uint32_t len = lenv;
             if (len > p.len_limit || len > TP) atomicOr(p.status, kStatusBadLength);   // (device-side lengths[] are only seen here)
             else {
               lds_add(lds_len, (len - 1u) * 4u, 1u);
@@ -1484,7 +1525,9 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             if (hits) {
               const uint32_t at = cand_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushers, 0u));
               if constexpr (W16)   // (the words as they stand: own 16 codes; the previous lane's word, of which the drain reads bits 0-17)
-                cand_q16[at] = make_uint4(ploU[u][1], prevU[u], hits | (lane_id << 16), rl[u]);
+                // (strided rows: + the length this lane holds — of the read that starts in it, else of the read it lies in — and
+                //  whether its first positions belong to the read before that one: the drain then needs no load)
+                cand_q16[at] = make_uint4(ploU[u][1], prevU[u], hits | (lane_id << 16) | (SV ? (nv[u] & 0x7FFFu) | (straddles ? 0x8000u : 0u) : 0u), rl[u]);   // (a pushing lane's row is in the list: hits != 0 needs n != 0)
               else
                 cand_q[at] = make_uint2(ploU[u][0], prev2 | (hits << 2) | lane10 | (rl[u] << 16));
             }

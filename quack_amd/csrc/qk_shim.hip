@@ -296,7 +296,7 @@ uint32_t choose_group(const qk_accum *a, uint64_t n_reads, uint32_t read_len, ui
 }
 
 int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged, bool gapped, bool aligned, Plan *pl,
-              bool base_aligned4 = true, bool strided = false, uint32_t addr_stride = 0, bool neutral_req = false) {
+              bool base_aligned4 = true, bool strided = false, uint32_t addr_stride = 0, bool neutral_req = false, bool sv_w16 = false) {
   const uint32_t T = (uint32_t)a->threads;
   // fixed-length reads: the distance between two reads — the read length, or (padded batches, round 4) the multiple of 4
   // above it: what decides whether every chunk starts on a dword is the stride, not the length
@@ -318,7 +318,9 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // (measured, round 3, same box: 10M x 300 + adapters 1.385 -> 1.27-1.29 ms, 1-20 kb reads on cache lines 0.575 -> 0.56;
   // fixed-length reads WITHOUT the adapter scan are memory-bound with 8 positions per lane at 70 VGPRs and lose 2-9 %
   // with 16 at 107 — 100 bp 0.341 -> 0.354 ms, 36 bp 0.140 -> 0.154 —, so they keep one chunk per lane)
-  bool w16 = !tuned && !strided && !getenv("QUACK_HIP_NO_W16") &&
+  // (strided batches — trimmed reads — take it too when their pads are neutral and the adapter scan is fused in: round 5)
+  const bool neutral_ok = neutral_req && strided && !tuned && T == 1024 && !getenv("QUACK_HIP_LENGTH_KERNEL") && !getenv("QUACK_HIP_NO_NEUTRAL");
+  bool w16 = !tuned && (!strided || (neutral_ok && sv_w16)) && !getenv("QUACK_HIP_NO_W16") &&
              (ragged ? aligned : (pl->fused_adapters && (fstride & 3u) == 0 && base_aligned4 && !getenv("QUACK_HIP_NO_ALIGN4") &&
                                   // short reads whose last pair would be half empty lose more lanes than the pairs save
                                   // (36 bp: 48 columns for 36 positions, 0.236 -> 0.251 ms; 76 bp 0.417 -> 0.383, 100 bp 0.521 -> 0.497)
@@ -426,7 +428,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
                                    : std::max<uint32_t>(1, std::min<uint32_t>(1024 / T, (uint32_t)(160 * 1024 / lds)));
   // strided batches with neutral pads (0xFF behind every read): the variant without tail masks — one tile, lengths counted in
   // the step loop (which is where a position's `valid` count comes from), the planner's own geometry
-  pl->neutral = neutral_req && strided && n_tiles == 1 && !tuned && T == 1024 && !getenv("QUACK_HIP_LENGTH_KERNEL") && !getenv("QUACK_HIP_NO_NEUTRAL");
+  pl->neutral = neutral_ok && n_tiles == 1;
   // strided batches without the adapter scan: the kernel is built for 64 VGPRs and runs two
   // workgroups per CU when the LDS holds two histograms (reads of up to ~190 bases)
   if (strided && !pl->fused_adapters && a->wgs_per_cu <= 0 && T == 1024) {
@@ -495,8 +497,15 @@ template <int T, int U, int PD>
 int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, bool aligned, bool strided, bool w16, dim3 grid,
                    size_t lds, hipStream_t st, bool neutral = false) {
   void (*k)(const qk::HistParams) = nullptr;
+  if (w16 && strided) {
+    // strided rows with neutral pads and the fused adapter scan (round 5): one tile, block b owns slice b
+    if constexpr (T == 1024 && PD == 2 && U == 1)
+      if (fixed && aligned && mode == 0 && adapt && neutral && hp.n_tiles == 1 && !hp.queue && !hp.static_split)
+        k = qk::hist_kernel<T, U, true, 0, true, PD, true, true, true, true, true>;
+    if (!k) return fail(QK_EINVAL, "the 16-positions-per-lane strided kernel is built for one-tile batches with neutral pads and adapters only");
+  } else
   if (w16) {
-    // 16 positions per lane: built for the step shapes the planner (or QUACK_HIP_W16_U / _PD) asks for
+    // 16 positions per lane: built for the step shapes the planner asks for
     if (aligned && mode == 0 && !strided) {
       if constexpr (T == 1024 && PD == 2 && U == 1) {
         const bool one = hp.n_tiles == 1 && !hp.queue && !hp.static_split;
@@ -663,15 +672,20 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   // (qk::HistParams::group); the reads that do not make a whole row run as a small batch of their own
   uint32_t group = 1;
   const uint32_t rstride = (strided || padded) ? stride : max_len;   // bytes between two reads of a fixed-stride batch
-  if (!d_off && !d_len && !no_group && n_reads >= 64) {
+  // (round 5) strided batches whose pads are neutral take the same kernel when the adapter scan is fused in — trimmed reads run
+  // with -a as a rule (/root/reference/images/makefile:8,14): a row is then whole strides, pads included
+  const bool sv16 = strided && (flags & QK_BATCH_NEUTRAL_PADS) && a->adapters && (stride & 3u) == 0 && base4 && stride >= 64u &&
+                    stride <= single_tile_cap(a, false, true);
+  const uint32_t glen = sv16 ? stride : max_len;   // positions of a read's slot that the kernel counts
+  if (!d_off && (!d_len || sv16) && !no_group && n_reads >= 64) {
     uint32_t row_cap = 0;
     for (;;) {
-      group = choose_group(a, n_reads, max_len, rstride, base4, row_cap);
+      group = choose_group(a, n_reads, glen, rstride, base4, row_cap);
       if (group <= 1) break;
-      const uint32_t row = (group - 1u) * rstride + max_len;
-      rc = make_plan(a, n_reads / group, row, false, false, false, &pl, base4, false, group * rstride);
+      const uint32_t row = (group - 1u) * rstride + glen;
+      rc = make_plan(a, n_reads / group, row, false, false, false, &pl, base4, sv16, group * rstride, sv16, sv16);
       if (rc == QK_OK && pl.w16 && pl.n_tiles == 1 && pl.fused_adapters && (uint64_t)pl.rw * (uint32_t)pl.unroll * group <= qk::kFhRing / 2u &&
-          (pl.bucket_log2 || !a->bucket_log2))
+          (pl.bucket_log2 || !a->bucket_log2) && (!sv16 || pl.neutral))
         break;
       row_cap = row - 1u;   // (the row does not fit beside the adapter tables after all: a shorter one)
     }
@@ -681,7 +695,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     if (rem) {
       const uint64_t head = n_reads - rem;
       rc = enqueue_batch(a, d_seq + head * rstride, d_qual + head * rstride, nullptr, d_hit ? d_hit + head : nullptr, rem, rem * (uint64_t)rstride,
-                         max_len, st, nullptr, 0, stride, /*no_group=*/true);
+                         max_len, st, d_len ? d_len + head : nullptr, d_len ? flags : 0u, stride, /*no_group=*/true);
       if (rc) return rc;
       n_reads = head;
       total_bytes = head * (uint64_t)rstride;
@@ -689,15 +703,20 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   } else {
     rc = make_plan(a, n_reads, strided ? stride : max_len, d_off != nullptr, d_off && d_len,
                    d_off && d_len && (flags & QK_BATCH_ALIGNED128), &pl, base4, strided, padded ? stride : 0u,
-                   strided && (flags & QK_BATCH_NEUTRAL_PADS));
+                   strided && (flags & QK_BATCH_NEUTRAL_PADS), sv16);
     if (rc) return rc;
+    if (sv16 && pl.w16 && (pl.n_tiles != 1 || !pl.neutral || (uint64_t)pl.rw * (uint32_t)pl.unroll > qk::kFhRing / 2u)) {
+      // (not the shape the 16-position strided kernel is built for after all)
+      rc = make_plan(a, n_reads, stride, false, false, false, &pl, base4, true, 0u, true, false);
+      if (rc) return rc;
+    }
   }
   if (strided) {
     // The strided kernel variant exists for the planner's own geometry only.  Under a tuning override
     // (QUACK_HIP_THREADS / _UNROLL / _PIPE / _NO_ALIGN4 / _ADAPT_PD / _ADAPT_U, qk_accum_configure) the same
     // reads run as gapped batches — starts[i] = i * stride written by a small kernel, lengths[] as they are —
     // in chunks below the 2 GiB a gapped batch may span.  Same counters, the ragged kernels' speed.
-    const bool native = pl.aligned && a->threads == 1024 && pl.pipe == 2 && pl.unroll == (pl.fused_adapters ? 2 : 1);
+    const bool native = pl.aligned && a->threads == 1024 && pl.pipe == 2 && pl.unroll == ((pl.fused_adapters && !pl.w16) ? 2 : 1);
     if (!native) pl.neutral = false;
     if (!native) {
       if (a->starts_scratch_reads < n_reads) {

@@ -105,21 +105,29 @@ def test_config3_at_150bp_padded_exact_on_every_read(monkeypatch):
         np.testing.assert_array_equal(sd.bases, want, err_msg=str(env))
 
 
-def test_trimmed_10M_strided_exact_on_every_read():
-    """the bench's trimmed-reads batch (70 % full length, the rest 120-149, stride 152 + lengths[]) against the
-    oracle on the same reads packed"""
+@pytest.mark.parametrize("workload", ["trimmed", "trimmed_adapters"])
+def test_trimmed_10M_strided_exact_on_every_read(workload):
+    """the bench's trimmed-reads batches (70 % full length, the rest 120-149, stride 152 + lengths[], 0xFF behind every read;
+    `trimmed_adapters`: the adapter table loaded, a quarter of the reads with a spliced adapter) against the oracle on the same
+    reads packed — submitted the way bench.py submits them (QK_BATCH_NEUTRAL_PADS: the kernel variants the bench line times)
+    AND without the promise (the variants that mask the tails)"""
     import bench
-    w = dict(bench.WORKLOADS["trimmed"])
-    b = bench.make_batch(torch, np, w, seed=7, device=torch.device("cuda", 0))
+    w = dict(bench.WORKLOADS[workload])
+    bits, ads = bench.synthetic_adapter_bits(np) if w["adapters"] else (None, None)
+    b = bench.make_batch(torch, np, w, seed=7, device=torch.device("cuda", 0), ads=ads)
     torch.cuda.synchronize()
-    with quack_amd.Accumulator(0) as acc:
-        acc.submit_device_strided(b["seq"], b["qual"], b["d_len"], b["n"], b["stride"], b["max_len"])
-        sd = acc.finish()
     hs, hq, off, m, bases = bench.host_sample(np, b, w, 1 << 62)
     assert m == b["n"] and bases == b["total"]
-    want, wn = ob.accumulate_batch_threads(hs, hq, off)
-    assert wn == b["n"] and sd.number_of_sequences == wn
-    np.testing.assert_array_equal(sd.bases, want)
+    want, wn = ob.accumulate_batch_threads(hs, hq, off, kmers=ob.kmers_from_seqs([bytes(a) for a in ads]) if ads is not None else None)
+    assert wn == b["n"]
+    for neutral in (True, False):
+        with quack_amd.Accumulator(0, bits) as acc:
+            acc.submit_device_strided(b["seq"], b["qual"], b["d_len"], b["n"], b["stride"], b["max_len"], neutral_pads=neutral)
+            sd = acc.finish()
+        assert sd.number_of_sequences == wn, neutral
+        np.testing.assert_array_equal(sd.bases, want, err_msg="neutral_pads=%s" % neutral)
+    if w["adapters"]:
+        assert want[:, 96].sum() > 1_000_000
 
 
 def test_config4_full_per_gpu_share_each_mate_exact():

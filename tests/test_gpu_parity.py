@@ -959,6 +959,52 @@ def test_strided_batches(n, lo, hi, stride, adapters):
     assert_same((sd.bases, want[1]), (3 * want[0], want[1]))
 
 
+@pytest.mark.parametrize("stride,lo,hi", [(64, 0, 64), (76, 30, 75), (100, 60, 100), (152, 120, 150), (152, 0, 152), (252, 200, 250),
+                                          (300, 280, 300), (352, 11, 352)])
+def test_strided_rows_with_adapters_sixteen_positions_per_lane(stride, lo, hi, monkeypatch):
+    """Round 5: trimmed reads WITH the adapter scan (quack.c:206-217 runs on every read whatever its length) — a strided batch
+    whose pads are 0xFF takes the 16-positions-per-lane kernel, rows of several reads where that fills the lanes: every group
+    size, reads of every length from empty to the whole stride (70 % of them the longest), an odd read count (the reads that do
+    not fill a last row are a launch of their own), adapters spliced in up to the last base; device-resident and through the
+    pinned slots; against the oracle on the same reads packed."""
+    import torch
+    rng = np.random.default_rng(stride * 1000 + lo)
+    n = 40001
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    bits = ob.kmers_to_bitset(k)
+    lens = rng.integers(lo, hi + 1, n)
+    lens[rng.random(n) < 0.7] = hi
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(off[-1])
+    seq = np.frombuffer(b"ACGTNacgt", np.uint8)[rng.integers(0, 9, total)].copy()
+    qual = (33 + rng.integers(1, 61, total)).astype(np.uint8)
+    for r in rng.integers(0, n, n // 3):
+        a, e = int(off[r]), int(off[r + 1])
+        if e - a > 12:
+            ad = np.frombuffer(ads[r % len(ads)], np.uint8)
+            at = a + int(rng.integers(0, e - a))
+            m = min(len(ad), e - at)
+            seq[at:at + m] = ad[:m]
+    want = ob.accumulate_batch(seq, qual, off, kmers=k)
+    assert want[0][:, 96].sum() > 100
+    s3, q3, l3 = strided_from_ragged(seq, qual, off, stride, fill=0xFF)
+    d_s3, d_q3 = torch.from_numpy(pad_for_device(s3)).cuda(), torch.from_numpy(pad_for_device(q3)).cuda()
+    d_l = torch.from_numpy(l3.astype(np.int32)).cuda()
+    torch.cuda.synchronize()
+    for env in ({}, {"QUACK_HIP_GROUP": "1"}, {"QUACK_HIP_GROUP": "2"}, {"QUACK_HIP_GROUP": "3"}, {"QUACK_HIP_GROUP": "4"}, {"QUACK_HIP_NO_W16": "1"}):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        with quack_amd.Accumulator(0, bits) as acc:
+            acc.submit_device_strided(d_s3, d_q3, d_l, n, stride, int(l3.max()), neutral_pads=True)
+            acc.submit_strided(s3, q3, l3, stride)       # (pinned slots: the library writes the pads itself)
+            sd = acc.finish()
+        for kk in env:
+            monkeypatch.delenv(kk)
+        assert sd.number_of_sequences == 2 * want[1], env
+        np.testing.assert_array_equal(sd.bases, 2 * want[0], err_msg=str(env))
+
+
 def test_neutral_pads_promise_is_checked_where_the_host_has_the_bytes():
     """qk_accum_commit_strided_flags(QK_BATCH_NEUTRAL_PADS) looks at the first and the last pad byte of every read"""
     import ctypes
