@@ -960,6 +960,10 @@ def main():
         if w.get("pad"):
             w["pad"] = (args.read_len + 3) & ~3
         w["label"] += " [read length overridden: %d]" % args.read_len
+    elif args.read_len and w.get("stride"):   # the trimmed workloads at another read length: 70 % full length, the rest down to 80 % of it
+        L = args.read_len
+        w["L"], w["ragged"], w["stride"] = L, (max(1, L * 4 // 5), L), (L + 3) & ~3
+        w["label"] += " [read length overridden: %d, trimmed down to %d, stride %d]" % (L, w["ragged"][0], w["stride"])
     if args.splice is not None and w.get("splice") is not None:
         w["splice"] = args.splice
         w["label"] += " [spliced share overridden: %g]" % args.splice

@@ -158,12 +158,17 @@ int qk_accum_submit_device_strided(qk_accum *acc, const void *d_seq, const void 
 int qk_accum_commit_strided(qk_accum *acc, uint64_t n_reads, uint32_t stride);
 /* QK_BATCH_NEUTRAL_PADS (round 4): the producer promises that the bytes behind every read's last base, up to the stride,
  * are 0xFF in both arrays.  Such a byte counts into a quality row the flush discards and matches none of T / C / G, so
- * the kernel runs without tail masks (a third of its instructions; 10M trimmed 150 bp reads 0.5300 -> 0.5178 ms); a position's content[A] comes from the lengths the kernel counts anyway.  The host tokenizer writes its strided
- * batches that way (quack_amd/host/reader.c) and qk_accum_submit_strided neutralises the pads on its way into the pinned
- * slot.  The pinned-slot commit checks the first and the last pad byte of every read (QK_EINVAL otherwise); a
- * device-resident batch is taken at its word — pads that are not 0xFF would be counted — unless QUACK_HIP_CHECK_PADS=1 is
- * set: the shim then checks every pad byte on the device first, and a violation fails the next qk_accum_sync (tests,
- * debugging a producer).  Same counters as without the flag. */
+ * the kernel runs without tail masks (a third of its instructions; 10M trimmed 150 bp reads 0.5300 -> 0.5178 ms); a
+ * position's content[A] comes from the lengths the kernel counts anyway.  With the adapter table loaded such a batch (stride a
+ * multiple of 4, 64 .. 352) takes the 16-positions-per-lane kernel, rows of several reads (round 5: 0.44 -> 0.59 of the HBM
+ * peak on trimmed 150 bp reads).  The host tokenizer writes its strided batches that way (quack_amd/host/reader.c) and
+ * qk_accum_submit_strided neutralises the pads on its way into the pinned slot.
+ * FAILURE MODE OF A BROKEN PROMISE: a pad byte that is T / C / G is counted into t / c / g while `valid` comes from the lengths,
+ * so content[A] = valid - t - c - g is silently WRONG (it underflows), rc 0.  What guards against it: the pinned-slot commit
+ * checks every pad byte of every read (QK_EINVAL otherwise); a device-resident batch has its pads verified by a kernel for the
+ * first two such batches of an accumulator — a violation fails the next qk_accum_sync / finish — and for every batch with
+ * QUACK_HIP_CHECK_PADS=1 (tests, debugging a producer); beyond that it is taken at its word.  Same counters as without the
+ * flag. */
 #define QK_BATCH_NEUTRAL_PADS 2u
 int qk_accum_submit_device_strided_flags(qk_accum *acc, const void *d_seq, const void *d_qual, const void *d_lengths,
                                          uint64_t n_reads, uint32_t stride, uint32_t max_len, uint32_t flags, void *hip_stream);

@@ -53,6 +53,22 @@ def hip():
     return _hip
 
 
+_hip_exp = None
+
+
+def hip_exp():
+    """libquack_hip_exp.so — the -DQK_EXPERIMENT build of the same source (QUACK_HIP_TUNE switches, kernel variants of launch
+    geometries the planner does not pick) — loaded beside the product's library with its own symbols first.  Tools and the
+    parity tests that cross-check those geometries only; nothing of the product links it."""
+    global _hip_exp
+    if _hip_exp is None:
+        path = os.path.join(_HERE, "libquack_hip_exp.so")
+        if not os.path.exists(path):
+            raise NativeLibraryMissing("%s not built: run `make exp` at the repository root" % path)
+        _hip_exp = bind_hip(ctypes.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND))
+    return _hip_exp
+
+
 def bind_hip(L):
     """argtypes of every symbol of include/quack_hip.h on a loaded library (hip() does this for the product's own;
     tools/ab_inproc.py binds a second build beside it)"""

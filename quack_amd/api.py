@@ -14,9 +14,9 @@ class HipUnavailable(RuntimeError):
     replaced by a CPU computation anywhere in this package."""
 
 
-def _check(rc):
+def _check(rc, lib=None):
     if rc != 0:
-        raise HipUnavailable("quack_hip error %d: %s" % (rc, _capi.hip().qk_last_error().decode()))
+        raise HipUnavailable("quack_hip error %d: %s" % (rc, (lib or _capi.hip()).qk_last_error().decode()))
 
 
 def device_count():
@@ -112,13 +112,21 @@ class Accumulator:
     one GPU.  Host batches are numpy arrays; device batches are anything with
     a data_ptr() (torch tensors on the accumulator's device)."""
 
-    def __init__(self, device=0, kmers=None, max_len_hint=0, _lib=None):
+    def __init__(self, device=0, kmers=None, max_len_hint=0, _lib=None, experiment=None):
+        """experiment: use the -DQK_EXPERIMENT build (libquack_hip_exp.so: QUACK_HIP_TUNE, configure()); by default that is the
+        case exactly when QUACK_HIP_TUNE is set — the product library reads no such switch"""
         self._h = ctypes.c_void_p()
-        self._L = _lib if _lib is not None else _capi.hip()   # (_lib: a second build bound with _capi.bind_hip, developer tools only)
+        if experiment is None:
+            experiment = bool(os.environ.get("QUACK_HIP_TUNE"))
+        # (_lib: a second build bound with _capi.bind_hip, developer tools only)
+        self._L = _lib if _lib is not None else (_capi.hip_exp() if experiment else _capi.hip())
         kp = kmers.ctypes.data if kmers is not None else None
         self._kmers = kmers  # keep alive during create
-        _check(self._L.qk_accum_create(ctypes.byref(self._h), device, kp, max_len_hint))
+        self._ck(self._L.qk_accum_create(ctypes.byref(self._h), device, kp, max_len_hint))
         self.device = device
+
+    def _ck(self, rc):
+        _check(rc, self._L)   # (the error text lives in the library that returned rc)
 
     def close(self):
         if self._h:
@@ -138,7 +146,7 @@ class Accumulator:
         self.close()
 
     def configure(self, threads=0, unroll=0, tile=0, wgs_per_cu=0):
-        _check(self._L.qk_accum_configure(self._h, threads, unroll, tile, wgs_per_cu))
+        self._ck(self._L.qk_accum_configure(self._h, threads, unroll, tile, wgs_per_cu))
 
     # -- host-resident batches (copied through the pinned double buffer) ----
     def submit(self, seq, qual, offsets):
@@ -148,14 +156,14 @@ class Accumulator:
         n = len(offsets) - 1
         if n < 0 or len(seq) != len(qual) or (n >= 0 and int(offsets[-1]) != len(seq)):
             raise ValueError("inconsistent batch arrays")
-        _check(self._L.qk_accum_submit(self._h, seq.ctypes.data, qual.ctypes.data, offsets.ctypes.data, n))
+        self._ck(self._L.qk_accum_submit(self._h, seq.ctypes.data, qual.ctypes.data, offsets.ctypes.data, n))
 
     def submit_fixed(self, seq, qual, read_len):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         qual = np.ascontiguousarray(qual, dtype=np.uint8)
         if read_len <= 0 or len(seq) % read_len or len(seq) != len(qual):
             raise ValueError("inconsistent fixed-length batch")
-        _check(self._L.qk_accum_submit_fixed(self._h, seq.ctypes.data, qual.ctypes.data, read_len,
+        self._ck(self._L.qk_accum_submit_fixed(self._h, seq.ctypes.data, qual.ctypes.data, read_len,
                                              len(seq) // read_len))
 
     def submit_strided(self, seq, qual, lengths, stride):
@@ -165,7 +173,7 @@ class Accumulator:
         lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
         if stride <= 0 or len(seq) != len(lengths) * stride or len(seq) != len(qual):
             raise ValueError("inconsistent strided batch")
-        _check(self._L.qk_accum_submit_strided(self._h, seq.ctypes.data, qual.ctypes.data, lengths.ctypes.data,
+        self._ck(self._L.qk_accum_submit_strided(self._h, seq.ctypes.data, qual.ctypes.data, lengths.ctypes.data,
                                                stride, len(lengths)))
 
     def submit_gapped(self, seq, qual, starts, lengths, aligned=False):
@@ -179,12 +187,12 @@ class Accumulator:
         hs, hq = ctypes.POINTER(ctypes.c_uint8)(), ctypes.POINTER(ctypes.c_uint8)()
         ho, hl = ctypes.POINTER(ctypes.c_uint64)(), ctypes.POINTER(ctypes.c_uint32)()
         capb, capr = ctypes.c_uint64(), ctypes.c_uint64()
-        _check(self._L.qk_accum_acquire(self._h, ctypes.byref(hs), ctypes.byref(hq), ctypes.byref(ho),
+        self._ck(self._L.qk_accum_acquire(self._h, ctypes.byref(hs), ctypes.byref(hq), ctypes.byref(ho),
                                         ctypes.byref(capb), ctypes.byref(capr)))
         if extent > capb.value or n > capr.value:
             self._L.qk_accum_commit(self._h, 0, 0, 0, 0)
             raise ValueError("batch larger than a pinned slot")
-        _check(self._L.qk_accum_slot_lengths(self._h, ctypes.byref(hl)))
+        self._ck(self._L.qk_accum_slot_lengths(self._h, ctypes.byref(hl)))
         ctypes.memmove(hs, seq.ctypes.data, extent)
         ctypes.memmove(hq, qual.ctypes.data, extent)
         ctypes.memmove(ho, starts.ctypes.data, 8 * n)
@@ -192,14 +200,14 @@ class Accumulator:
         rc = self._L.qk_accum_commit_gapped(self._h, n, extent, QK_BATCH_ALIGNED128 if aligned else 0)
         if rc:
             self._L.qk_accum_commit(self._h, 0, 0, 0, 0)   # give the slot back
-            _check(rc)
+            self._ck(rc)
 
     # -- device-resident batches (bench / torch plumbing) --------------------
     def submit_device_gapped(self, d_seq, d_qual, d_starts, d_lengths, n_reads, extent_bytes, max_len,
                              aligned=False, stream=None):
         """starts: int64/uint64[n] device tensor, lengths: int32/uint32[n]; see
         qk_accum_submit_device_gapped"""
-        _check(self._L.qk_accum_submit_device_gapped(
+        self._ck(self._L.qk_accum_submit_device_gapped(
             self._h, d_seq.data_ptr(), d_qual.data_ptr(), d_starts.data_ptr(), d_lengths.data_ptr(),
             n_reads, extent_bytes, max_len, QK_BATCH_ALIGNED128 if aligned else 0, stream))
 
@@ -207,7 +215,7 @@ class Accumulator:
         """read r at [r*stride, r*stride + lengths[r]); lengths: int32/uint32[n] device tensor; stride % 4 == 0;
         neutral_pads: the caller promises 0xFF behind every read's last base (QK_BATCH_NEUTRAL_PADS: the kernel without tail
         masks); see qk_accum_submit_device_strided"""
-        _check(self._L.qk_accum_submit_device_strided_flags(
+        self._ck(self._L.qk_accum_submit_device_strided_flags(
             self._h, d_seq.data_ptr(), d_qual.data_ptr(), d_lengths.data_ptr() if d_lengths is not None else None,
             n_reads, stride, max_len, QK_BATCH_NEUTRAL_PADS if neutral_pads else 0, stream))
 
@@ -219,62 +227,62 @@ class Accumulator:
     def padded_stride(self, read_len):
         """the stride the library wants for uniform reads of read_len on this accumulator (0: packed)"""
         s = ctypes.c_uint32()
-        _check(self._L.qk_accum_padded_stride(self._h, read_len, ctypes.byref(s)))
+        self._ck(self._L.qk_accum_padded_stride(self._h, read_len, ctypes.byref(s)))
         return s.value
 
     def commit_padded(self, n_reads, read_len, stride):
         """enqueue the acquired slot as a padded fixed-length batch (read r written at r*stride)"""
-        _check(self._L.qk_accum_commit_padded(self._h, n_reads, read_len, stride))
+        self._ck(self._L.qk_accum_commit_padded(self._h, n_reads, read_len, stride))
 
     def submit_device(self, d_seq, d_qual, d_offsets, n_reads, total_bytes, max_len, stream=None):
         """d_* expose data_ptr(); buffers need QK_TAIL_SLACK readable bytes
         after total_bytes.  Enqueues only."""
-        _check(self._L.qk_accum_submit_device(
+        self._ck(self._L.qk_accum_submit_device(
             self._h, d_seq.data_ptr(), d_qual.data_ptr(),
             d_offsets.data_ptr() if d_offsets is not None else None,
             n_reads, total_bytes, max_len, stream))
 
     def sync(self):
-        _check(self._L.qk_accum_sync(self._h))
+        self._ck(self._L.qk_accum_sync(self._h))
 
     def stats(self):
         a, b = ctypes.c_uint64(), ctypes.c_uint64()
-        _check(self._L.qk_accum_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        self._ck(self._L.qk_accum_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
     def table_words(self):
         n = ctypes.c_uint64()
-        _check(self._L.qk_accum_table_words(self._h, ctypes.byref(n)))
+        self._ck(self._L.qk_accum_table_words(self._h, ctypes.byref(n)))
         return n.value
 
     def reserve(self, max_len):
-        _check(self._L.qk_accum_reserve(self._h, max_len))
+        self._ck(self._L.qk_accum_reserve(self._h, max_len))
 
     def export_table(self, d_dst, stream=None):
-        _check(self._L.qk_accum_export_table(self._h, d_dst.data_ptr(), stream))
+        self._ck(self._L.qk_accum_export_table(self._h, d_dst.data_ptr(), stream))
 
     def import_table(self, d_src, max_len, stream=None):
-        _check(self._L.qk_accum_import_table(self._h, d_src.data_ptr(), max_len, stream))
+        self._ck(self._L.qk_accum_import_table(self._h, d_src.data_ptr(), max_len, stream))
 
     def timing(self, on=True):
         """on: False / True, or N > 1 = HIP events around every Nth batch only"""
-        _check(self._L.qk_accum_timing_enable(self._h, int(on)))
+        self._ck(self._L.qk_accum_timing_enable(self._h, int(on)))
 
     def timing_read(self):
         ms, n = ctypes.c_double(), ctypes.c_uint64()
-        _check(self._L.qk_accum_timing_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        self._ck(self._L.qk_accum_timing_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
     def timing_read_batch(self):
         """(histogram-kernel ms, all-kernels-of-the-batch ms, launches) since timing(True)"""
         ms, bms, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
-        _check(self._L.qk_accum_timing_read_batch(self._h, ctypes.byref(ms), ctypes.byref(bms), ctypes.byref(n)))
+        self._ck(self._L.qk_accum_timing_read_batch(self._h, ctypes.byref(ms), ctypes.byref(bms), ctypes.byref(n)))
         return ms.value, bms.value, n.value
 
     def timing_read_range(self):
         """(shortest, longest) timed histogram-kernel launch in ms"""
         lo, hi = ctypes.c_double(), ctypes.c_double()
-        _check(self._L.qk_accum_timing_read_range(self._h, ctypes.byref(lo), ctypes.byref(hi)))
+        self._ck(self._L.qk_accum_timing_read_range(self._h, ctypes.byref(lo), ctypes.byref(hi)))
         return lo.value, hi.value
 
     # -- the pinned double buffer itself (qk_accum_acquire / qk_accum_commit): what the C host feed drives
@@ -284,21 +292,21 @@ class Accumulator:
         hs, hq = ctypes.POINTER(ctypes.c_uint8)(), ctypes.POINTER(ctypes.c_uint8)()
         ho = ctypes.POINTER(ctypes.c_uint64)()
         capb, capr = ctypes.c_uint64(), ctypes.c_uint64()
-        _check(self._L.qk_accum_acquire(self._h, ctypes.byref(hs), ctypes.byref(hq), ctypes.byref(ho),
+        self._ck(self._L.qk_accum_acquire(self._h, ctypes.byref(hs), ctypes.byref(hq), ctypes.byref(ho),
                                         ctypes.byref(capb), ctypes.byref(capr)))
         return (np.ctypeslib.as_array(hs, shape=(capb.value,)), np.ctypeslib.as_array(hq, shape=(capb.value,)),
                 np.ctypeslib.as_array(ho, shape=(capr.value + 1,)))
 
     def commit(self, n_reads, total_bytes, read_len=0):
         """enqueue H2D + kernels of the acquired slot; read_len > 0: fixed-length batch (offsets unused)"""
-        _check(self._L.qk_accum_commit(self._h, n_reads, total_bytes, 0 if read_len else 1, read_len))
+        self._ck(self._L.qk_accum_commit(self._h, n_reads, total_bytes, 0 if read_len else 1, read_len))
 
     def finish(self):
         a, b = ctypes.c_uint64(), ctypes.c_uint64()
-        _check(self._L.qk_accum_finish(self._h, None, 0, ctypes.byref(a), ctypes.byref(b)))
+        self._ck(self._L.qk_accum_finish(self._h, None, 0, ctypes.byref(a), ctypes.byref(b)))
         out = np.zeros(a.value * QK_N_ROWS, dtype=np.uint64)
         if a.value:
-            _check(self._L.qk_accum_finish(self._h, out.ctypes.data, a.value, ctypes.byref(a), ctypes.byref(b)))
+            self._ck(self._L.qk_accum_finish(self._h, out.ctypes.data, a.value, ctypes.byref(a), ctypes.byref(b)))
         return SequenceData(out, b.value)
 
 
@@ -307,7 +315,8 @@ def allreduce(accumulators):
     (same-device shards by an add kernel, distinct devices by one RCCL
     all-reduce); afterwards each holds the global table."""
     arr = (ctypes.c_void_p * len(accumulators))(*[a._h for a in accumulators])
-    _check(_capi.hip().qk_accum_allreduce(arr, len(accumulators)))
+    L = accumulators[0]._L if accumulators else _capi.hip()   # (accumulators of one library)
+    _check(L.qk_accum_allreduce(arr, len(accumulators)), L)
 
 
 def pad_for_device(arr):

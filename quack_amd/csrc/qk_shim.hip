@@ -72,6 +72,34 @@ int env_int(const char *name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
+// Experiment switches (round 5): the product library reads no environment variable that selects another launch geometry or
+// kernel variant — only QUACK_VERBOSE, QUACK_HIP_BATCH_MB, QUACK_HIP_CHECK_PADS and the QUACK_HIP_NO_* / _UNFUSED_ADAPTERS
+// fallbacks.  Everything the tools and the parity tests use to force a geometry the planner would not pick lives in ONE variable,
+//     QUACK_HIP_TUNE="key=value,key,..."      (group=2, small_ring, pipe=3, threads=512, ...)
+// which only a -DQK_EXPERIMENT build parses (quack_amd/libquack_hip_exp.so, tools/kbench); that build also carries the kernel
+// variants those geometries need.  In the product build every switch is a compile-time constant.
+#ifdef QK_EXPERIMENT
+const char *tune_find(const char *key) {   // -> the text behind "key=" ("" for a bare key), or nullptr
+  const char *s = getenv("QUACK_HIP_TUNE");
+  const size_t kl = strlen(key);
+  while (s && *s) {
+    const char *e = strchr(s, ',');
+    const size_t len = e ? (size_t)(e - s) : strlen(s);
+    if (len >= kl && strncmp(s, key, kl) == 0 && (len == kl || s[kl] == '=')) return len == kl ? "" : s + kl + 1;
+    s = e ? e + 1 : nullptr;
+  }
+  return nullptr;
+}
+bool tune_on(const char *key) { return tune_find(key) != nullptr; }
+int tune_int(const char *key, int dflt) {
+  const char *v = tune_find(key);
+  return (v && *v) ? atoi(v) : (v ? 1 : dflt);
+}
+#else
+inline bool tune_on(const char *) { return false; }
+inline int tune_int(const char *, int dflt) { return dflt; }
+#endif
+
 struct Slot {
   uint8_t *h_seq = nullptr, *h_qual = nullptr;
   uint64_t *h_off = nullptr;
@@ -147,6 +175,7 @@ struct qk_accum {
   hipEvent_t side_done = nullptr;                   // behind a pre-pass on `side`: the histogram kernel waits for it
   hipEvent_t set_free[kSets] = {};     // behind the histogram kernel that read set i
   bool set_busy[kSets] = {};
+  unsigned pads_checked = 0;          // neutral-pad batches whose pads were verified on the device (the first two always are)
   uint32_t *d_status = nullptr;       // device word: bit 0 = an "aligned" batch was not aligned
   bool status_armed = false;
   hipEvent_t order_ev = nullptr;
@@ -274,12 +303,12 @@ uint32_t single_tile_cap(const qk_accum *a, bool ragged, bool w16) {
 // when nothing is gained.  Only under the planner's own geometry, with the first hits in the LDS ring.
 uint32_t choose_group(const qk_accum *a, uint64_t n_reads, uint32_t read_len, uint32_t stride, bool base_aligned4, uint32_t row_cap = 0) {
   if (!a->adapters || getenv("QUACK_HIP_UNFUSED_ADAPTERS") || getenv("QUACK_HIP_NO_GROUP") || getenv("QUACK_HIP_NO_W16") ||
-      getenv("QUACK_HIP_NO_ALIGN4") || getenv("QUACK_HIP_SEPARATE_COUNT") || getenv("QUACK_HIP_ADAPT_PD") || getenv("QUACK_HIP_ADAPT_U"))
+      getenv("QUACK_HIP_NO_ALIGN4") || tune_on("separate_count") || tune_on("adapt_pd") || tune_on("adapt_u"))
     return 1;
   if (a->unroll || a->pipe || a->threads != 1024 || a->tile > 0 || a->wgs_per_cu > 0) return 1;
   if ((stride & 3u) || stride < 16u || read_len < 11u || !base_aligned4) return 1;
   const uint32_t cap = single_tile_cap(a, false, true);   // positions of the widest one-tile row
-  const int forced = env_int("QUACK_HIP_GROUP", 0);       // (tests: a given group size, where it fits)
+  const int forced = tune_int("group", 0);       // (tests: a given group size, where it fits)
   uint32_t best = 1;
   double best_cost = 0;
   for (uint32_t g = 1; g <= 8u && g <= n_reads; ++g) {
@@ -319,13 +348,13 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // fixed-length reads WITHOUT the adapter scan are memory-bound with 8 positions per lane at 70 VGPRs and lose 2-9 %
   // with 16 at 107 — 100 bp 0.341 -> 0.354 ms, 36 bp 0.140 -> 0.154 —, so they keep one chunk per lane)
   // (strided batches — trimmed reads — take it too when their pads are neutral and the adapter scan is fused in: round 5)
-  const bool neutral_ok = neutral_req && strided && !tuned && T == 1024 && !getenv("QUACK_HIP_LENGTH_KERNEL") && !getenv("QUACK_HIP_NO_NEUTRAL");
+  const bool neutral_ok = neutral_req && strided && !tuned && T == 1024 && !tune_on("length_kernel") && !getenv("QUACK_HIP_NO_NEUTRAL");
   bool w16 = !tuned && (!strided || (neutral_ok && sv_w16)) && !getenv("QUACK_HIP_NO_W16") &&
              (ragged ? aligned : (pl->fused_adapters && (fstride & 3u) == 0 && base_aligned4 && !getenv("QUACK_HIP_NO_ALIGN4") &&
                                   // short reads whose last pair would be half empty lose more lanes than the pairs save
                                   // (36 bp: 48 columns for 36 positions, 0.236 -> 0.251 ms; 76 bp 0.417 -> 0.383, 100 bp 0.521 -> 0.497)
                                   (max_len >= 64 || round_up(max_len, 16) == round_up(max_len, 8))));
-  if (getenv("QUACK_HIP_W16_ALWAYS") && !tuned && !strided && !ragged && (fstride & 3u) == 0 && base_aligned4) w16 = true;   // (tests: the plain fixed-length variant)
+  if (tune_on("w16_always") && !tuned && !strided && !ragged && (fstride & 3u) == 0 && base_aligned4) w16 = true;   // (tests: the plain fixed-length variant)
   // widest tile whose LDS image (histogram + adapter tables + staged read list) fits
   const uint32_t single_cap = single_tile_cap(a, ragged, w16);
   uint32_t cap = a->tile > 0 ? std::max<uint32_t>(8, (uint32_t)a->tile / 8 * 8) : single_cap;
@@ -365,8 +394,8 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   if (!ragged && (fstride & 3u) == 0 && base_aligned4 && T == 1024 && !a->unroll && !a->pipe &&
       !getenv("QUACK_HIP_NO_ALIGN4"))
     pl->aligned = true;
-  if (pl->aligned && !ragged && pl->fused_adapters) pl->pipe = env_int("QUACK_HIP_ADAPT_PD", pl->pipe), pl->unroll = env_int("QUACK_HIP_ADAPT_U", pl->unroll);
-  if (!pl->aligned || (pl->fused_adapters && (getenv("QUACK_HIP_ADAPT_PD") || getenv("QUACK_HIP_ADAPT_U")))) w16 = false;
+  if (pl->aligned && !ragged && pl->fused_adapters) pl->pipe = tune_int("adapt_pd", pl->pipe), pl->unroll = tune_int("adapt_u", pl->unroll);
+  if (!pl->aligned || (pl->fused_adapters && (tune_on("adapt_pd") || tune_on("adapt_u")))) w16 = false;
   if (w16) {
     // a lane owns two adjacent chunks: tiles of whole chunk pairs (fixed-length reads: the columns behind the
     // read hold the next read's bytes and are never flushed, as before), one read per lane and step with the
@@ -385,7 +414,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   pl->rw = (pl->fused_adapters ? T / 64 * (w16 ? 63 : 62) : T) / (pl->ch / (w16 ? 2 : 1) + pl->halo);
   // replicas of the quality counters (bank balance, see qk::hist_replicas)
   pl->replicas = qk::hist_replicas(pl->ch);
-  if (const int r = env_int("QUACK_HIP_REPLICAS", 0)) pl->replicas = std::min<uint32_t>((uint32_t)r, pl->replicas);
+  if (const int r = tune_int("replicas", 0)) pl->replicas = std::min<uint32_t>((uint32_t)r, pl->replicas);
   const uint64_t step = (uint64_t)pl->rw * (uint32_t)pl->unroll;
   // the exact table next to the histogram, if it fits (it never narrows a tile: without it
   // the queued candidates are checked against the global table)
@@ -409,15 +438,15 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // 10M x 150 + adapters, same box: 2048 words (a fold every 10 steps) 0.6474 ms, 8192 words 0.6268.  A ring of 8192 words is
   // worth more than counter replicas (which measure nothing with the adapter scan: 0.6479 against 0.6474 ms): they go first.
   pl->fh_words = qk::kFhRing;
-  if (pl->fused_adapters && !ragged && !getenv("QUACK_HIP_SMALL_RING")) {
-    const uint32_t most = (uint32_t)std::max(2048, std::min((int)qk::kFhRingMax, env_int("QUACK_HIP_RING_WORDS", (int)qk::kFhRingMax)));
+  if (pl->fused_adapters && !ragged && !tune_on("small_ring")) {
+    const uint32_t most = (uint32_t)std::max(2048, std::min((int)qk::kFhRingMax, tune_int("ring_words", (int)qk::kFhRingMax)));
     auto ring_for = [&](uint32_t replicas) {
       uint32_t wds = qk::kFhRing;
       while (wds * 2 <= most && qk::hist_lds_bytes(pl->ch, replicas, true, pl->bucket_log2, false, pl->stage_reads, w16, wds * 2) <= 160 * 1024)
         wds *= 2;
       return wds;
     };
-    while (pl->replicas > 1 && ring_for(pl->replicas) < std::min<uint32_t>(most, 8192u) && !getenv("QUACK_HIP_REPLICAS")) --pl->replicas;
+    while (pl->replicas > 1 && ring_for(pl->replicas) < std::min<uint32_t>(most, 8192u) && !tune_on("replicas")) --pl->replicas;
     pl->fh_words = ring_for(pl->replicas);
   }
   size_t lds = qk::hist_lds_bytes(pl->ch, pl->replicas, pl->fused_adapters, pl->bucket_log2, ragged, pl->stage_reads, w16, pl->fh_words);
@@ -432,7 +461,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // strided batches without the adapter scan: the kernel is built for 64 VGPRs and runs two
   // workgroups per CU when the LDS holds two histograms (reads of up to ~190 bases)
   if (strided && !pl->fused_adapters && a->wgs_per_cu <= 0 && T == 1024) {
-    if (2 * lds > 160 * 1024 && !getenv("QUACK_HIP_SV_ONE_WG")) {   // fewer replicas, if that admits the second workgroup
+    if (2 * lds > 160 * 1024 && !tune_on("sv_one_wg")) {   // fewer replicas, if that admits the second workgroup
       const size_t lds1 = qk::hist_lds_bytes(pl->ch, 1, false, 0, ragged, pl->stage_reads);
       if (2 * lds1 <= 160 * 1024) {
         pl->replicas = 1;
@@ -448,7 +477,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
   // workgroup flushes its LDS histogram only when its tile changes.
   const uint64_t resident = (uint64_t)a->n_cu * wgs;
   pl->dynamic = n_tiles > 1;
-  uint64_t want_items = pl->dynamic ? resident * (uint64_t)std::max(1, env_int("QUACK_HIP_OVERSUB", 16)) : resident;
+  uint64_t want_items = pl->dynamic ? resident * (uint64_t)std::max(1, tune_int("oversub", 16)) : resident;
   uint64_t n_slices = std::max<uint64_t>(1, want_items / n_tiles);
   uint64_t rps = (n_reads + n_slices - 1) / n_slices;
   rps = round_up(std::max<uint64_t>(rps, 1), step);
@@ -486,7 +515,7 @@ int make_plan(const qk_accum *a, uint64_t n_reads, uint32_t max_len, bool ragged
 uint32_t padded_stride_for(const qk_accum *a, uint32_t read_len) {
   if ((read_len & 3u) == 0 || getenv("QUACK_HIP_NO_PAD")) return 0;
   if (a->unroll || a->pipe || a->threads != 1024 || getenv("QUACK_HIP_NO_ALIGN4")) return 0;   // (the aligned variants are the planner's own)
-  const bool always = getenv("QUACK_HIP_PAD_ALWAYS") != nullptr;
+  const bool always = tune_on("pad_always");
   if (!a->adapters && !always) return 0;
   if (read_len < 16u && !always) return 0;
   return (read_len + 3u) & ~3u;
@@ -539,10 +568,22 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
       if (!adapt) k = qk::hist_kernel<T, U, false, 0, false, PD, true>;
 #endif
   }
+  // The product library holds the variants the planner itself asks for (make_plan without overrides): fixed length (1,2) plain and
+  // (2,2) with the adapter scan, packed ragged (4,1), reads on cache lines (2,2), 16 positions per lane (1,2), strided.  Every other
+  // step shape belongs to the -DQK_EXPERIMENT build (QUACK_HIP_TUNE, qk_accum_configure).
+#ifdef QK_EXPERIMENT
+  constexpr bool kAll = true;
+#else
+  constexpr bool kAll = false;
+#endif
   if (!w16 && !strided && aligned && fixed && mode == 0) {
-    if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 2))
-      k = adapt ? qk::hist_kernel<T, U, true, 0, true, PD, true> : qk::hist_kernel<T, U, true, 0, false, PD, true>;
-    if constexpr (T == 1024 && PD > 2)
+    if constexpr (T == 1024 && PD == 2 && (U == 1 || U == 2)) {
+      if constexpr (kAll || U == 2)
+        if (adapt) k = qk::hist_kernel<T, U, true, 0, true, PD, true>;
+      if constexpr (kAll || U == 1)
+        if (!adapt) k = qk::hist_kernel<T, U, true, 0, false, PD, true>;
+    }
+    if constexpr (kAll && T == 1024 && PD > 2)
       if (adapt) k = qk::hist_kernel<T, U, true, 0, true, PD, true>;
   }
   if constexpr (PD > 2) {
@@ -550,10 +591,17 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
   } else
   if (k) {
   } else if (adapt) {
-    if (mode == 0) k = fixed ? qk::hist_kernel<T, U, true, 0, true, PD> : qk::hist_kernel<T, U, false, 0, true, PD>;
+    if (mode == 0) {
+      if constexpr (kAll || (T == 1024 && U == 2 && PD == 2))
+        if (fixed) k = qk::hist_kernel<T, U, true, 0, true, PD>;
+      if constexpr (kAll || (T == 1024 && U == 4 && PD == 1))
+        if (!fixed) k = qk::hist_kernel<T, U, false, 0, true, PD>;
+    }
   } else if (fixed) {
     switch (mode) {
-      case 0: k = qk::hist_kernel<T, U, true, 0, false, PD>; break;
+      case 0:
+        if constexpr (kAll || (T == 1024 && U == 1 && PD == 2)) k = qk::hist_kernel<T, U, true, 0, false, PD>;
+        break;
 #ifdef QK_ABLATION
       case 1: k = qk::hist_kernel<T, U, true, 1, false, PD>; break;
       case 2: k = qk::hist_kernel<T, U, true, 2, false, PD>; break;
@@ -561,9 +609,12 @@ int launch_hist_tu(const qk::HistParams &hp, bool fixed, int mode, bool adapt, b
 #endif
     }
   } else {
-    if (mode == 0) k = qk::hist_kernel<T, U, false, 0, false, PD>;
+    if constexpr (kAll || (T == 1024 && U == 4 && PD == 1))
+      if (mode == 0) k = qk::hist_kernel<T, U, false, 0, false, PD>;
   }
-  if (!k) return fail(QK_EINVAL, "kernel variant not built (mode %d)", mode);
+  if (!k) return fail(QK_EINVAL, "kernel variant not built: threads %d, unroll %d, pipe %d%s%s (mode %d) — the product library holds the "
+                      "planner's own step shapes, the experiment build (libquack_hip_exp.so, QUACK_HIP_TUNE) the others", T, U, PD,
+                      fixed ? ", fixed length" : ", ragged", adapt ? ", adapters" : "", mode);
   {
     // the kernels use absolute LDS addresses (qk::qhist_add; the fused scan's filter at
     // LDS byte 0, qk::lds_abs_u8): the dynamic segment must start at byte 0
@@ -611,13 +662,16 @@ int launch_hist(qk_accum *a, const qk::HistParams &hp, const Plan &pl, bool fixe
   dim3 grid((unsigned)pl.n_blocks);
 #define QK_TU(TT, UU, PP) \
   if (a->threads == TT && pl.unroll == UU && pl.pipe == PP) return launch_hist_tu<TT, UU, PP>(hp, fixed, mode, adapt, pl.aligned, strided, pl.w16, grid, lds, st, neutral);
-  QK_TU(1024, 4, 1) QK_TU(1024, 2, 1) QK_TU(1024, 1, 1)
-  QK_TU(1024, 4, 2) QK_TU(1024, 2, 2) QK_TU(1024, 1, 2)
+  QK_TU(1024, 4, 1) QK_TU(1024, 2, 2) QK_TU(1024, 1, 2)
+#ifdef QK_EXPERIMENT
+  QK_TU(1024, 2, 1) QK_TU(1024, 1, 1) QK_TU(1024, 4, 2)
   QK_TU(1024, 2, 3) QK_TU(1024, 2, 4) QK_TU(1024, 1, 4)
   QK_TU(512, 4, 1) QK_TU(512, 2, 1) QK_TU(512, 1, 1)
   QK_TU(256, 4, 1) QK_TU(256, 2, 1)
+#endif
 #undef QK_TU
-  return fail(QK_EINVAL, "unsupported threads/unroll/pipe %d/%d/%d", a->threads, pl.unroll, pl.pipe);
+  return fail(QK_EINVAL, "unsupported threads/unroll/pipe %d/%d/%d (the product library holds the planner's own step shapes; "
+              "others: the experiment build)", a->threads, pl.unroll, pl.pipe);
 }
 
 hipEvent_t get_event(qk_accum *a) {
@@ -674,7 +728,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   const uint32_t rstride = (strided || padded) ? stride : max_len;   // bytes between two reads of a fixed-stride batch
   // (round 5) strided batches whose pads are neutral take the same kernel when the adapter scan is fused in — trimmed reads run
   // with -a as a rule (/root/reference/images/makefile:8,14): a row is then whole strides, pads included
-  const bool sv16 = strided && (flags & QK_BATCH_NEUTRAL_PADS) && a->adapters && (stride & 3u) == 0 && base4 && stride >= 64u &&
+  const bool sv16 = strided && (flags & QK_BATCH_NEUTRAL_PADS) && a->adapters && (stride & 3u) == 0 && base4 && stride >= 16u &&
                     stride <= single_tile_cap(a, false, true);
   const uint32_t glen = sv16 ? stride : max_len;   // positions of a read's slot that the kernel counts
   if (!d_off && (!d_len || sv16) && !no_group && n_reads >= 64) {
@@ -690,15 +744,13 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
       row_cap = row - 1u;   // (the row does not fit beside the adapter tables after all: a shorter one)
     }
   }
+  uint64_t rem = 0, rem_head = 0;   // the reads that do not fill a last row: a small launch of their own, inside this batch's timing events (below)
   if (group > 1) {
-    const uint64_t rem = n_reads % group;
+    rem = n_reads % group;
     if (rem) {
-      const uint64_t head = n_reads - rem;
-      rc = enqueue_batch(a, d_seq + head * rstride, d_qual + head * rstride, nullptr, d_hit ? d_hit + head : nullptr, rem, rem * (uint64_t)rstride,
-                         max_len, st, d_len ? d_len + head : nullptr, d_len ? flags : 0u, stride, /*no_group=*/true);
-      if (rc) return rc;
-      n_reads = head;
-      total_bytes = head * (uint64_t)rstride;
+      rem_head = n_reads - rem;
+      n_reads = rem_head;
+      total_bytes = rem_head * (uint64_t)rstride;
     }
   } else {
     rc = make_plan(a, n_reads, strided ? stride : max_len, d_off != nullptr, d_off && d_len,
@@ -729,7 +781,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
       }
       if ((rc = order_after_previous(a, st))) return rc;   // the scratch is shared by the accumulator's launches
       uint64_t per_chunk = std::max<uint64_t>(1, 0x7FFFFF00ull / stride);
-      if (const int t = env_int("QUACK_HIP_STRIDED_CHUNK_READS", 0)) per_chunk = std::min<uint64_t>(per_chunk, (uint64_t)t);   // (tests: several chunks without 2 GiB)
+      if (const int t = tune_int("strided_chunk_reads", 0)) per_chunk = std::min<uint64_t>(per_chunk, (uint64_t)t);   // (tests: several chunks without 2 GiB)
       const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, 4096);
       hipLaunchKernelGGL(qk::strided_starts_kernel, dim3(blocks), dim3(256), 0, st, a->d_starts_scratch, n_reads, per_chunk, stride,
                          d_len, max_len, a->d_status);
@@ -745,7 +797,10 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     }
   }
   if ((rc = order_after_previous(a, st))) return rc;
-  if (strided && pl.neutral && getenv("QUACK_HIP_CHECK_PADS")) {   // (the promise, verified on request: see qk::pads_check_kernel)
+  // the promise of a device-resident batch: verified for the first batches of every accumulator (a producer that writes its pads
+  // wrongly does so from the start) and for every batch on request (QUACK_HIP_CHECK_PADS=1: tests, debugging a producer)
+  if (strided && pl.neutral && (a->pads_checked < 2 || getenv("QUACK_HIP_CHECK_PADS"))) {
+    a->pads_checked++;
     const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, 4096);
     hipLaunchKernelGGL(qk::pads_check_kernel, dim3(blocks), dim3(256), 0, st, d_seq, d_qual, d_len, n_reads, stride, a->d_status);
     QK_HIP(hipGetLastError());
@@ -766,8 +821,8 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     // count kernel get their own pair of events around the whole batch
     // (not a fused one-tile adapter batch: the histogram kernel is all of it, and two more events would add their own
     // ~10 us of stream time to what they measure)
-    const bool one_kernel = pl.fused_adapters && pl.n_tiles == 1 && !getenv("QUACK_HIP_SEPARATE_COUNT");
-    if (pl.n_tiles > 1 || (a->adapters && !one_kernel) || (strided && getenv("QUACK_HIP_LENGTH_KERNEL"))) {
+    const bool one_kernel = pl.fused_adapters && pl.n_tiles == 1 && !tune_on("separate_count");
+    if (pl.n_tiles > 1 || (a->adapters && !one_kernel) || (strided && tune_on("length_kernel"))) {
       tl.b0 = get_event(a);
       // (nothing runs behind the histogram kernel unless the adapter hits are counted by kernels of their own: the batch
       // then ends where the kernel does, one event for both)
@@ -838,7 +893,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   int set = -1;
   // (one tile, the strided kernel variant itself: the lane that owns a read's first chunk counts its length inside the step
   // loop — the separate pass over lengths[] was 24 us per 10M reads, 4.5 % of the batch)
-  const bool count_in_loop = strided && pl.n_tiles == 1 && !getenv("QUACK_HIP_LENGTH_KERNEL");
+  const bool count_in_loop = strided && pl.n_tiles == 1 && !tune_on("length_kernel");
   if (strided && !count_in_loop) {
     // strided batches have no staging pass that could count the lengths on the way
     // (ragged batches of several tiles: hist_kernel counts a read's length in the tile it ends in).
@@ -898,7 +953,7 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     // what crossing into another tile costs a workgroup (clearing and flushing a histogram), in read-tiles: measured on
     // 1-20 kb reads inside one process (tools/ab_inproc.py): 0 -> 0.5822 ms, 150 0.5812, 300 0.5738, 450 0.5746,
     // 600 0.5737, 900 0.5755, 1200 0.5766, 2400 0.5815, 4800 0.5835
-    hp.tile_overhead = (uint32_t)std::max(0, env_int("QUACK_HIP_TILE_OVERHEAD", 400));
+    hp.tile_overhead = (uint32_t)std::max(0, tune_int("tile_overhead", 400));
     const uint64_t step = (uint64_t)pl.rw * (uint32_t)pl.unroll;
     hp.reads_per_slice = (qk::kMaxReadsPerSlice - step) / step * step;
   }
@@ -907,10 +962,15 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
   hp.halo = pl.halo;
 
   // one tile: the histogram kernel resets first_hit[] and takes the kmer_count of its own reads
-  hp.count_in_kernel = pl.fused_adapters && pl.n_tiles == 1 && !getenv("QUACK_HIP_SEPARATE_COUNT");
+  hp.count_in_kernel = pl.fused_adapters && pl.n_tiles == 1 && !tune_on("separate_count");
   // (Round 3 had an opt-in that handed the two events to the dispatch packet itself — hipExtLaunchKernelGGL, 0.5 % of a step —
   // and one of three full test runs with it stopped making progress; never root-caused, so round 4 removed it.)
   if (timed) QK_HIP(hipEventRecord(tl.t0, st));
+  if (rem) {   // (this launch used to sit outside the events while its reads were in the counters)
+    rc = enqueue_batch(a, d_seq + rem_head * rstride, d_qual + rem_head * rstride, nullptr, d_hit ? d_hit + rem_head : nullptr, rem, rem * (uint64_t)rstride,
+                       max_len, st, d_len ? d_len + rem_head : nullptr, d_len ? flags : 0u, stride, /*no_group=*/true);
+    if (rc) return rc;
+  }
   if (pl.fused_adapters && !hp.count_in_kernel) QK_HIP(hipMemsetAsync(d_hit, 0xFF, n_reads * sizeof(uint32_t), st));
   rc = launch_hist(a, hp, pl, d_off == nullptr, g_ablation_mode, pl.fused_adapters, st, strided);
   if (rc) return rc;
@@ -1137,11 +1197,11 @@ int qk_debug_plan(uint64_t n_reads, uint32_t max_len, int ragged, int adapters, 
   a.n_cu = n_cu > 0 ? n_cu : 256;
   a.adapters = adapters != 0;
   a.bucket_log2 = adapters ? bucket_log2 : 0;
-  a.threads = env_int("QUACK_HIP_THREADS", a.threads);
-  a.unroll = env_int("QUACK_HIP_UNROLL", a.unroll);
-  a.pipe = env_int("QUACK_HIP_PIPE", a.pipe);
-  a.tile = env_int("QUACK_HIP_TILE", a.tile);
-  a.wgs_per_cu = env_int("QUACK_HIP_WGS_PER_CU", a.wgs_per_cu);
+  a.threads = tune_int("threads", a.threads);
+  a.unroll = tune_int("unroll", a.unroll);
+  a.pipe = tune_int("pipe", a.pipe);
+  a.tile = tune_int("tile", a.tile);
+  a.wgs_per_cu = tune_int("wgs_per_cu", a.wgs_per_cu);
   Plan pl;
   int rc = make_plan(&a, n_reads, max_len, ragged != 0, gapped != 0, aligned != 0, &pl);
   if (rc) return rc;
@@ -1197,11 +1257,11 @@ int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
       break;
     }
     a->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    a->threads = env_int("QUACK_HIP_THREADS", a->threads);
-    a->unroll = env_int("QUACK_HIP_UNROLL", a->unroll);
-    a->pipe = env_int("QUACK_HIP_PIPE", a->pipe);
-    a->tile = env_int("QUACK_HIP_TILE", a->tile);
-    a->wgs_per_cu = env_int("QUACK_HIP_WGS_PER_CU", a->wgs_per_cu);
+    a->threads = tune_int("threads", a->threads);
+    a->unroll = tune_int("unroll", a->unroll);
+    a->pipe = tune_int("pipe", a->pipe);
+    a->tile = tune_int("tile", a->tile);
+    a->wgs_per_cu = tune_int("wgs_per_cu", a->wgs_per_cu);
     lap.mark("device");
     if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking) != hipSuccess ||
@@ -1275,7 +1335,7 @@ void qk_accum_destroy(qk_accum *a) {
     if (tl.b1 != tl.t1) (void)hipEventDestroy(tl.b1);
   }
   for (auto e : a->event_pool) (void)hipEventDestroy(e);
-  if (getenv("QUACK_HIP_DEBUG_ADDR"))   // (where this accumulator's buffers lay: tools/ab_inproc.py --addresses)
+  if (tune_on("debug_addr"))   // (where this accumulator's buffers lay: tools/ab_inproc.py --addresses)
     fprintf(stderr, "quack_hip: acc table %p order %p %p reach %p %p queues %p stream %p side %p\n", (void *)a->d_table, (void *)a->d_order[0],
             (void *)a->d_order[1], (void *)a->d_reach[0], (void *)a->d_reach[1], (void *)a->d_queues, (void *)a->stream, (void *)a->side);
   if (a->d_queues) (void)hipFree(a->d_queues);
@@ -1658,10 +1718,13 @@ int qk_accum_commit_strided_flags(qk_accum *a, uint64_t n_reads, uint32_t stride
     const uint32_t l = s.h_len[i];
     if (l > stride) return fail(QK_EINVAL, "read %llu is longer than the stride", (unsigned long long)i);
     max_len = std::max(max_len, l);
-    // the promise is checked where that is cheap — the first and the last pad byte of every read (the host has the bytes)
+    // the promise is checked where the host has the bytes: every pad byte of every read (a few bytes per read — a pad
+    // that is T / C / G would be counted while `valid` comes from the lengths: content[A] would underflow silently)
     if ((flags & QK_BATCH_NEUTRAL_PADS) && l < stride) {
       const uint8_t *ps = s.h_seq + i * (uint64_t)stride, *pq = s.h_qual + i * (uint64_t)stride;
-      if ((ps[l] & ps[stride - 1] & pq[l] & pq[stride - 1]) != 0xFF)
+      uint8_t all = 0xFF;
+      for (uint32_t k = l; k < stride; ++k) all &= ps[k] & pq[k];
+      if (all != 0xFF)
         return fail(QK_EINVAL, "read %llu: QK_BATCH_NEUTRAL_PADS promised 0xFF behind the read's last base", (unsigned long long)i);
     }
   }

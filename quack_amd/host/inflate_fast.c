@@ -26,6 +26,8 @@
 #define LITLEN_BITS 11
 #define DIST_BITS 8
 #define MULTI_BITS QKH_MULTI_BITS
+/* the fast loop takes four literal-run lookups from one refill of >= 56 bits, and a table entry's "bits to consume" field is 6 bits wide */
+_Static_assert(4 * QKH_MULTI_BITS <= 56 && QKH_MULTI_BITS <= 14 && QKH_MULTI_BITS >= 9, "QKH_MULTI_BITS: four lookups must fit one 56-bit refill");
 #define MAX_CODE_LEN 15
 
 /* table entry: bits 0-4 code length to consume, 5-7 kind, 8-12 extra bits

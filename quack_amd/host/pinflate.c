@@ -39,6 +39,16 @@
 #include "inflate_fast.h"
 
 enum { WIN = 32768, MAX_THREADS = 32 };
+/* a spin-wait's breather (the x86 builtin alone kept the host library from building anywhere else) */
+static inline void cpu_relax(void) {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ volatile("yield");
+#else
+  __asm__ volatile("" ::: "memory");
+#endif
+}
 /* memory bounds: a slice that inflates past SPEC_MAX bytes is not worth speculating on (FASTQ is 4-5x;
  * this is 32x) and is decoded in order instead; buffers that grew past KEEP_MAX are given back after use */
 #define SPEC_MAX ((size_t)32 << 20)
@@ -149,7 +159,12 @@ static void speculate(qkh_pinflate *p, unsigned k, pslot *s, qkh_inflate *z, spe
   r->n = n;
 }
 
-static __attribute__((noinline)) void resolve(const uint16_t *src, uint8_t *dst, size_t n, const uint8_t *lut) {
+/* markers -> bytes: dst[i] = lut[src[i]] (lut: identity below 256, the previous window from 0x8000).
+ * In FASTQ the markers are the few bytes of a record that were copied out of the unknown window (and copies of those copies:
+ * the `@r...` of every header line) — a run of 32 elements is free of them nine times out of ten, and such a run is narrowed
+ * by two vector instructions instead of 32 table look-ups.  Measured on one thread (tools/inflate_bench, "worker stages"):
+ * 1.9 GB/s -> see profiles/r05_inflate_stages.log; the pass was a seventh of what a decoder thread does with a slice. */
+static void resolve_scalar(const uint16_t *src, uint8_t *dst, size_t n, const uint8_t *lut) {
   size_t i = 0;
   for (; i + 4 <= n; i += 4) {
     dst[i] = lut[src[i]];
@@ -159,6 +174,36 @@ static __attribute__((noinline)) void resolve(const uint16_t *src, uint8_t *dst,
   }
   for (; i < n; i++) dst[i] = lut[src[i]];
 }
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void resolve_avx2(const uint16_t *src, uint8_t *dst, size_t n, const uint8_t *lut) {
+  const __m256i high = _mm256_set1_epi16((short)0xFF00);
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const __m256i a = _mm256_loadu_si256((const __m256i *)(src + i));
+    const __m256i b = _mm256_loadu_si256((const __m256i *)(src + i + 16));
+    if (_mm256_testz_si256(_mm256_or_si256(a, b), high)) {   /* 32 plain bytes */
+      const __m256i pk = _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8);   /* (packus works per 128-bit lane) */
+      _mm256_storeu_si256((__m256i *)(dst + i), pk);
+    } else {
+      for (size_t j = i; j < i + 32; j++) dst[j] = lut[src[j]];
+    }
+  }
+  for (; i < n; i++) dst[i] = lut[src[i]];
+}
+#endif
+void qkh_resolve16(const uint16_t *src, uint8_t *dst, size_t n, const uint8_t *lut) {
+#if defined(__x86_64__) && defined(__GNUC__)
+  static int have = -1;   /* (benign race: every thread computes the same answer) */
+  if (have < 0) have = __builtin_cpu_supports("avx2") ? 1 : 0;
+  if (have) {
+    resolve_avx2(src, dst, n, lut);
+    return;
+  }
+#endif
+  resolve_scalar(src, dst, n, lut);
+}
+#define resolve qkh_resolve16
 
 typedef struct {
   qkh_pinflate *p;
@@ -198,7 +243,7 @@ static void *worker_main(void *arg) {
     for (int spins = 0; spins < 20000; spins++) {
       const unsigned cn = atomic_load_explicit(&p->chain_next, memory_order_acquire);
       if (cn == k || k - cn > 2u) break;
-      __builtin_ia32_pause();
+      cpu_relax();
     }
     pthread_mutex_lock(&p->mu);
     while (!p->stop && p->chain_next != k) pthread_cond_wait(&p->cv, &p->mu);

@@ -518,6 +518,22 @@ static size_t pgzip_slice(size_t file_len, int threads) {
   s &= ~(((size_t)256 << 10) - 1u);
   if (s < ((size_t)1 << 20)) s = (size_t)1 << 20;
   if (s > ((size_t)4 << 20)) s = (size_t)4 << 20;
+  /* ... within a memory budget: pinflate keeps threads + 4 slots of ~15 bytes per compressed byte — 36 slots of 4 MiB
+   * slices are 2.2 GB of resident buffers.  The budget: 2.5 GB, a quarter of the cgroup's memory limit if that is less
+   * (QUACK_PGZIP_MEM_MB overrides); slices shrink down to 1 MiB to stay inside it (2 MiB slices cost the feed ~10 %). */
+  {
+    const char *m = getenv("QUACK_PGZIP_MEM_MB");
+    size_t budget = (size_t)2560 << 20;
+    FILE *f = fopen("/sys/fs/cgroup/memory.max", "r");
+    if (f) {
+      unsigned long long lim = 0;
+      if (fscanf(f, "%llu", &lim) == 1 && lim > 0 && lim / 4u < budget) budget = (size_t)(lim / 4u);   /* ("max": no limit) */
+      fclose(f);
+    }
+    if (m && atoi(m) > 0) budget = (size_t)atoi(m) << 20;
+    const size_t slots = (size_t)(threads > 0 ? threads : 1) + 4u;
+    while (s > ((size_t)1 << 20) && s * 15u * slots > budget) s -= (size_t)256 << 10;
+  }
   return s;
 }
 

@@ -93,7 +93,7 @@ def test_config3_at_150bp_padded_exact_on_every_read(monkeypatch):
     want, wn = ob.accumulate_batch_threads(hs, hq, read_len=L, kmers=k)
     assert wn == n and 0.2 * n < want[:, 96].sum() <= n
     torch.cuda.synchronize()
-    for env in ({}, {"QUACK_HIP_NO_GROUP": "1"}, {"QUACK_HIP_SMALL_RING": "1"}):
+    for env in ({}, {"QUACK_HIP_NO_GROUP": "1"}, {"QUACK_HIP_TUNE": "small_ring=1"}):
         for kk, v in env.items():
             monkeypatch.setenv(kk, v)
         with quack_amd.Accumulator(0, bits) as acc:

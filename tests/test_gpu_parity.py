@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 def hip_table(seq, qual, offsets=None, read_len=0, kmers_bits=None, chunks=1, **cfg):
-    with quack_amd.Accumulator(0, kmers_bits) as acc:
+    # (a launch geometry of the caller's choosing — configure() — is the experiment build's business; so is QUACK_HIP_TUNE)
+    with quack_amd.Accumulator(0, kmers_bits, experiment=True if cfg else None) as acc:
         if cfg:
             acc.configure(**cfg)
         if offsets is None:
@@ -73,7 +74,7 @@ def test_adapters_fixed(L):
 
 @pytest.mark.parametrize("adapters", [False, True], ids=["plain", "adapters"])
 def test_sixteen_positions_per_lane_every_shape(adapters, monkeypatch):
-    monkeypatch.setenv("QUACK_HIP_W16_ALWAYS", "1")      # (the planner picks it by itself only with the adapter scan)
+    monkeypatch.setenv("QUACK_HIP_TUNE", "w16_always=1")      # (the planner picks it by itself only with the adapter scan)
     """fixed-length reads of a multiple of 4 bases run with 16 positions per lane (hist_kernel W16: two adjacent
     chunks per lane, one dwordx4 per array, odd chunk counts rounded up to whole pairs, one feeder lane per wave,
     one halo lane in front of a tile, per-lane candidate entries of 16 windows): every read length 4..128, lengths
@@ -121,7 +122,7 @@ def test_padded_fixed_length_every_length(adapters, monkeypatch):
     import torch
     overridden = [e for e in os.environ if e.startswith("QUACK_HIP_")]      # (tools/stress_gpu.sh runs this file under overrides)
     if not adapters:
-        monkeypatch.setenv("QUACK_HIP_PAD_ALWAYS", "1")   # (the feeds pad by themselves only with the adapter scan)
+        monkeypatch.setenv("QUACK_HIP_TUNE", "pad_always=1")   # (the feeds pad by themselves only with the adapter scan)
     ads = synth.synthetic_adapters()
     k = ob.kmers_from_seqs(ads) if adapters else None
     bits = ob.kmers_to_bitset(k) if adapters else None
@@ -168,7 +169,7 @@ def test_grouped_rows_every_group_size(forced, monkeypatch):
     seam between two reads — which must not count), packed and padded strides; and QUACK_HIP_NO_GROUP agrees"""
     import torch
     if forced:
-        monkeypatch.setenv("QUACK_HIP_GROUP", forced)
+        monkeypatch.setenv("QUACK_HIP_TUNE", "group=" + str(forced))
     ads = synth.synthetic_adapters()
     k = ob.kmers_from_seqs(ads)
     bits = ob.kmers_to_bitset(k)
@@ -207,7 +208,7 @@ def test_grouped_rows_every_group_size(forced, monkeypatch):
         hits += int(want[0][:, 96].sum())
         stride = (L + 3) & ~3
         s2, q2 = padded_layout(seq, qual, n, L, stride, seed=L)
-        for env in ({}, {"QUACK_HIP_NO_GROUP": "1"}, {"QUACK_HIP_SMALL_RING": "1"}) if forced is None else ({},):
+        for env in ({}, {"QUACK_HIP_NO_GROUP": "1"}, {"QUACK_HIP_TUNE": "small_ring=1"}) if forced is None else ({},):
             for kk, v in env.items():
                 monkeypatch.setenv(kk, v)
             with quack_amd.Accumulator(0, bits) as acc:
@@ -256,12 +257,12 @@ def test_padded_batches_through_the_pinned_slots_and_under_overrides(monkeypatch
     s2, q2 = padded_layout(seq, qual, 6000, 150, 152)
     import torch
     d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
-    for cfg, env in ((dict(threads=512), {}), (dict(unroll=2), {}), ({}, {"QUACK_HIP_PIPE": "1"}), ({}, {"QUACK_HIP_NO_ALIGN4": "1"}),
-                     ({}, {"QUACK_HIP_NO_W16": "1"}), ({}, {"QUACK_HIP_UNFUSED_ADAPTERS": "1"}), ({}, {"QUACK_HIP_SEPARATE_COUNT": "1"}),
+    for cfg, env in ((dict(threads=512), {}), (dict(unroll=2), {}), ({}, {"QUACK_HIP_TUNE": "pipe=1"}), ({}, {"QUACK_HIP_NO_ALIGN4": "1"}),
+                     ({}, {"QUACK_HIP_NO_W16": "1"}), ({}, {"QUACK_HIP_UNFUSED_ADAPTERS": "1"}), ({}, {"QUACK_HIP_TUNE": "separate_count=1"}),
                      ({}, {"QUACK_HIP_NO_PAD": "1"}), (dict(tile=64), {})):
         for kk, v in env.items():
             monkeypatch.setenv(kk, v)
-        with quack_amd.Accumulator(0, bits) as acc:
+        with quack_amd.Accumulator(0, bits, experiment=True if cfg else None) as acc:
             if cfg:
                 acc.configure(**cfg)
             acc.submit_device_padded(d_s, d_q, 6000, 150, 152)
@@ -293,7 +294,7 @@ def test_sixteen_positions_per_lane_on_and_off(monkeypatch):
             monkeypatch.delenv(kk)
     # without the adapter scan fixed-length reads keep 8 positions per lane (faster: memory-bound at 70 VGPRs); the
     # 16-position build of that shape exists and is forced here
-    monkeypatch.setenv("QUACK_HIP_W16_ALWAYS", "1")
+    monkeypatch.setenv("QUACK_HIP_TUNE", "w16_always=1")
     for L in (4, 36, 100, 300, 580):
         s2, q2 = synth.fixed(3000, L, seed=L)
         assert_same(hip_table(s2, q2, read_len=L), ob.accumulate_batch(s2, q2, read_len=L))
@@ -320,7 +321,7 @@ def test_every_tile_width_and_counter_replica_count(monkeypatch, replicas):
     """1..64 chunks per read: every layout of the quality counters (sets of columns, byte rotation per read
     row, replicas summed by the flush — qk::hist_replicas), with the planner's replica count and with fewer"""
     if replicas:
-        monkeypatch.setenv("QUACK_HIP_REPLICAS", replicas)
+        monkeypatch.setenv("QUACK_HIP_TUNE", "replicas=" + str(replicas))
     for L in [3, 8, 15, 16, 17, 24, 33, 47, 56, 64, 79, 90, 101, 125, 149, 176, 211, 250, 255, 256, 301, 390, 448, 509]:
         n = 2500 if L < 200 else 900
         seq, qual = synth.fixed(n, L, seed=L, q_lo=1, q_hi=90)
@@ -399,7 +400,7 @@ def test_fused_and_separate_adapter_paths_agree(shape, monkeypatch):
     assert_same(hip_table(seq, qual, off, read_len=L, kmers_bits=bits), want)
     monkeypatch.setenv("QUACK_HIP_UNFUSED_ADAPTERS", "1")
     assert_same(hip_table(seq, qual, off, read_len=L, kmers_bits=bits), want)
-    monkeypatch.setenv("QUACK_HIP_TILE", "64")             # many tiles, halo lanes at every seam
+    monkeypatch.setenv("QUACK_HIP_TUNE", "tile=64")             # many tiles, halo lanes at every seam
     monkeypatch.delenv("QUACK_HIP_UNFUSED_ADAPTERS")
     assert_same(hip_table(seq, qual, off, read_len=L, kmers_bits=bits), want)
 
@@ -708,8 +709,7 @@ def test_software_pipelined_variants_are_equivalent(monkeypatch, unroll, pipe):
     """QUACK_HIP_PIPE=2: the next step's loads are issued before the current
     step is consumed.  Automatic for fixed-length batches; forced here through
     every path (ragged staging, several tiles, fused adapters, short reads)"""
-    monkeypatch.setenv("QUACK_HIP_UNROLL", unroll)
-    monkeypatch.setenv("QUACK_HIP_PIPE", pipe)
+    monkeypatch.setenv("QUACK_HIP_TUNE", "unroll=%s,pipe=%s" % (unroll, pipe))
     ads = synth.synthetic_adapters()
     k = ob.kmers_from_seqs(ads)
     bits = ob.kmers_to_bitset(k)
@@ -959,7 +959,7 @@ def test_strided_batches(n, lo, hi, stride, adapters):
     assert_same((sd.bases, want[1]), (3 * want[0], want[1]))
 
 
-@pytest.mark.parametrize("stride,lo,hi", [(64, 0, 64), (76, 30, 75), (100, 60, 100), (152, 120, 150), (152, 0, 152), (252, 200, 250),
+@pytest.mark.parametrize("stride,lo,hi", [(16, 0, 16), (20, 9, 19), (36, 0, 36), (52, 40, 50), (64, 0, 64), (76, 30, 75), (100, 60, 100), (152, 120, 150), (152, 0, 152), (252, 200, 250),
                                           (300, 280, 300), (352, 11, 352)])
 def test_strided_rows_with_adapters_sixteen_positions_per_lane(stride, lo, hi, monkeypatch):
     """Round 5: trimmed reads WITH the adapter scan (quack.c:206-217 runs on every read whatever its length) — a strided batch
@@ -992,7 +992,7 @@ def test_strided_rows_with_adapters_sixteen_positions_per_lane(stride, lo, hi, m
     d_s3, d_q3 = torch.from_numpy(pad_for_device(s3)).cuda(), torch.from_numpy(pad_for_device(q3)).cuda()
     d_l = torch.from_numpy(l3.astype(np.int32)).cuda()
     torch.cuda.synchronize()
-    for env in ({}, {"QUACK_HIP_GROUP": "1"}, {"QUACK_HIP_GROUP": "2"}, {"QUACK_HIP_GROUP": "3"}, {"QUACK_HIP_GROUP": "4"}, {"QUACK_HIP_NO_W16": "1"}):
+    for env in ({}, {"QUACK_HIP_TUNE": "group=1"}, {"QUACK_HIP_TUNE": "group=2"}, {"QUACK_HIP_TUNE": "group=3"}, {"QUACK_HIP_TUNE": "group=4"}, {"QUACK_HIP_NO_W16": "1"}):
         for kk, v in env.items():
             monkeypatch.setenv(kk, v)
         with quack_amd.Accumulator(0, bits) as acc:
@@ -1069,8 +1069,8 @@ def test_strided_rejects_bad_geometry():
 
 
 @pytest.mark.parametrize("cfg,env", [(dict(threads=512), {}), (dict(unroll=2), {}), (dict(threads=256, unroll=2, tile=64), {}),
-                                     ({}, {"QUACK_HIP_PIPE": "1"}), ({}, {"QUACK_HIP_NO_ALIGN4": "1"}),
-                                     ({}, {"QUACK_HIP_ADAPT_PD": "3"}), ({}, {"QUACK_HIP_UNFUSED_ADAPTERS": "1"})])
+                                     ({}, {"QUACK_HIP_TUNE": "pipe=1"}), ({}, {"QUACK_HIP_NO_ALIGN4": "1"}),
+                                     ({}, {"QUACK_HIP_TUNE": "adapt_pd=3"}), ({}, {"QUACK_HIP_UNFUSED_ADAPTERS": "1"})])
 def test_strided_batches_under_tuning_overrides(cfg, env, monkeypatch):
     """the strided kernel variant exists for the planner's own geometry; under an override the same reads run as
     gapped batches (starts written on the device) — round 2 failed with QK_EINVAL here, and so did the CLI on
@@ -1093,7 +1093,7 @@ def test_strided_batches_under_tuning_overrides(cfg, env, monkeypatch):
     s2, q2, lens = strided_from_ragged(seq, qual, off, stride)
     for kmers, bits in ((None, None), (k, ob.kmers_to_bitset(k))):
         want = ob.accumulate_batch(seq, qual, off, kmers=kmers)
-        with quack_amd.Accumulator(0, bits) as acc:
+        with quack_amd.Accumulator(0, bits, experiment=True if cfg else None) as acc:
             if cfg:
                 acc.configure(**cfg)
             acc.submit_strided(s2, q2, lens, stride)
@@ -1108,14 +1108,14 @@ def test_strided_batches_under_tuning_overrides(cfg, env, monkeypatch):
 def test_strided_fallback_in_several_chunks(monkeypatch):
     """a strided batch restated as gapped ones is cut where a gapped batch would pass 2 GiB; here at 3000 reads"""
     import torch
-    monkeypatch.setenv("QUACK_HIP_STRIDED_CHUNK_READS", "3000")
+    monkeypatch.setenv("QUACK_HIP_TUNE", "strided_chunk_reads=3000")
     ads = synth.synthetic_adapters()
     k = ob.kmers_from_seqs(ads)
     n, stride = 10000, 152
     seq, qual, off = synth.ragged(n, 90, 150, seed=78, q_lo=1, q_hi=60)
     s2, q2, lens = strided_from_ragged(seq, qual, off, stride)
     want = ob.accumulate_batch(seq, qual, off, kmers=k)
-    with quack_amd.Accumulator(0, ob.kmers_to_bitset(k)) as acc:
+    with quack_amd.Accumulator(0, ob.kmers_to_bitset(k), experiment=True) as acc:
         acc.configure(unroll=2)
         d_s, d_q = torch.from_numpy(pad_for_device(s2)).cuda(), torch.from_numpy(pad_for_device(q2)).cuda()
         acc.submit_device_strided(d_s, d_q, torch.from_numpy(lens.astype(np.int32)).cuda(), n, stride, int(lens.max()))

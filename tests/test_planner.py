@@ -95,3 +95,39 @@ def test_rows_of_several_reads():
                 lanes1 = -(-read_len // 16) * 16 / read_len
                 lanesg = p["tile_pos"] / (p["group"] * read_len)
                 assert lanesg < lanes1 * 0.985, (read_len, p)                          # ... and only where it pays
+
+
+def test_experiment_switches_live_in_the_experiment_build_only(monkeypatch):
+    """Round 5: the product library reads no switch that selects another launch geometry — QUACK_HIP_TUNE is parsed by the
+    -DQK_EXPERIMENT build alone (libquack_hip_exp.so), which the Python mirror loads exactly when the variable is set; the old
+    per-switch variables are gone from both."""
+    X = _capi.hip_exp()
+    for lib in (L, X):
+        lib.qk_debug_group.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
+
+    def group(lib):
+        out = (ctypes.c_uint64 * 8)()
+        assert lib.qk_debug_group(1_000_000, 150, 152, 9, out) == 0
+        return out[0]
+
+    def threads(lib):
+        out = (ctypes.c_uint64 * 16)()
+        assert lib.qk_debug_plan(1_000_000, 150, 0, 0, 0, 0, 0, 256, out) == 0
+        return dict(zip(KEYS, out))["n_blocks"], dict(zip(KEYS, out))["unroll"]
+
+    assert group(L) == 2 and group(X) == 2            # the planner's own choice: rows of two 150 bp reads
+    base = threads(L)
+    monkeypatch.setenv("QUACK_HIP_TUNE", "group=1,unroll=4")
+    assert group(L) == 2 and group(X) == 1            # only the experiment build listens
+    assert threads(L) == base and threads(X)[1] == 4
+    monkeypatch.setenv("QUACK_HIP_GROUP", "1")        # (round 4's variable: nobody listens any more)
+    monkeypatch.delenv("QUACK_HIP_TUNE")
+    assert group(L) == 2 and group(X) == 2
+    # ... and the strings of the product library hold no experiment switch
+    import re
+    blob = open(_capi.hip()._name, "rb").read()
+    names = set(re.findall(rb"QUACK_[A-Z0-9_]+", blob))
+    allowed = {b"QUACK_VERBOSE", b"QUACK_HIP_BATCH_MB", b"QUACK_HIP_BATCH_KB", b"QUACK_HIP_CHECK_PADS", b"QUACK_HIP_RCCL_ALWAYS",
+               b"QUACK_HIP_UNFUSED_ADAPTERS", b"QUACK_HIP_TUNE"}   # (QUACK_HIP_TUNE: named in an error message, never read)
+    extra = {n for n in names if n not in allowed and not n.startswith(b"QUACK_HIP_NO_")}
+    assert not extra, extra

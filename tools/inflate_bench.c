@@ -49,6 +49,49 @@ int main(int argc, char **argv) {
     printf("inflate_fast: %zu bytes in %.3f s = %.1f MB/s (x%02x)\n", total, dt, total / dt / 1e6, crc);
     free(z);
   }
+  /* what a pinflate.c worker does with a slice, stage by stage, on one thread: the 16-bit (marker) decode, markers -> bytes,
+   * CRC-32, line index — in blocks of 16 MiB of output like a 4 MiB slice's */
+  {
+    enum { OUT16 = 16 << 20 };
+    uint16_t *b16 = malloc((HIST + OUT16 + 64) * sizeof *b16);
+    uint8_t *b8 = malloc(OUT16 + 64), *lut = malloc(65536);
+    uint32_t *nl = NULL;
+    size_t cap_nl = 0;
+    for (unsigned i = 0; i < 65536; i++) lut[i] = (uint8_t)i;
+    qkh_inflate *z = malloc(sizeof *z);
+    qkh_inflate_init(z, data, st.st_size);
+    size_t total = 0, hist = 0;
+    double t_dec = 0, t_res = 0, t_crc = 0, t_nl = 0;
+    uint32_t crc = 0;
+    for (;;) {
+      double t0 = now();
+      size_t n = 0;
+      for (;;) {
+        z->tl_n = 0;
+        long got = qkh_inflate_read16(z, b16 + HIST + n, OUT16 - n, hist + n);
+        if (got > 0) n += (size_t)got;
+        if (n == OUT16 || (got <= 0 && !qkh_inflate_log_full(z))) break;
+      }
+      double t1 = now();
+      if (!n) break;
+      extern void qkh_resolve16(const uint16_t *src, uint8_t *dst, size_t n, const uint8_t *lut);
+      qkh_resolve16(b16 + HIST, b8, n, lut);
+      double t2 = now();
+      crc = qkh_crc32(crc, b8, n);
+      double t3 = now();
+      size_t lines = qkh_index_lines(b8, n, &nl, &cap_nl);
+      double t4 = now();
+      (void)lines;
+      t_dec += t1 - t0, t_res += t2 - t1, t_crc += t3 - t2, t_nl += t4 - t3;
+      total += n;
+      size_t keep = n < HIST ? n : HIST;
+      memmove(b16 + HIST - keep, b16 + HIST + n - keep, keep * sizeof *b16);
+      hist = hist + n < HIST ? hist + n : HIST;
+    }
+    printf("worker stages: %zu bytes; decode16 %.3f s = %.1f MB/s, resolve %.3f s = %.1f MB/s, crc32 %.3f s = %.1f MB/s, line index %.3f s = %.1f MB/s; all %.1f MB/s (crc %08x)\n",
+           total, t_dec, total / t_dec / 1e6, t_res, total / t_res / 1e6, t_crc, total / t_crc / 1e6, t_nl, total / t_nl / 1e6,
+           total / (t_dec + t_res + t_crc + t_nl) / 1e6, crc);
+  }
   {
     gzFile g = gzopen(argv[1], "rb");
     gzbuffer(g, 1 << 20);

@@ -8,11 +8,13 @@ mkdir -p gpurun_out; : > gpurun_out/stress.log
 # (strided batches run under every override too: the shim restates them as gapped batches when the strided
 # kernel variant is not built for the geometry)
 K="not cli and not launch_configurations and not pipelined and not tuning_overrides and not under_overrides"
-for e in "QUACK_HIP_TILE=64" "QUACK_HIP_THREADS=512" "QUACK_HIP_TILE=128 QUACK_HIP_THREADS=256 QUACK_HIP_UNROLL=2" \
-         "QUACK_HIP_PIPE=2 QUACK_HIP_UNROLL=2" "QUACK_HIP_UNFUSED_ADAPTERS=1" "QUACK_HIP_REPLICAS=1" "QUACK_HIP_REPLICAS=2" \
-         "QUACK_HIP_ADAPT_PD=3" "QUACK_HIP_ADAPT_PD=4 QUACK_HIP_ADAPT_U=1" "QUACK_HIP_SEPARATE_COUNT=1" \
-         "QUACK_HIP_NO_GROUP=1" "QUACK_HIP_GROUP=2" "QUACK_HIP_SMALL_RING=1" "QUACK_HIP_RING_WORDS=4096" "QUACK_HIP_NO_PAD=1" "QUACK_HIP_PAD_ALWAYS=1" \
-         "QUACK_HIP_NO_W16=1" "QUACK_HIP_NO_SIDE=1" "QUACK_HIP_NO_TABLE32=1" "QUACK_HIP_TILE_OVERHEAD=0" "QUACK_HIP_LENGTH_KERNEL=1"; do
+# (round 5: the experiment switches live in ONE variable, QUACK_HIP_TUNE, which only the -DQK_EXPERIMENT build parses — the Python
+#  mirror loads libquack_hip_exp.so whenever it is set; the QUACK_HIP_NO_* fallbacks are the product library's own)
+for e in "QUACK_HIP_TUNE=tile=64" "QUACK_HIP_TUNE=threads=512" "QUACK_HIP_TUNE=tile=128,threads=256,unroll=2" \
+         "QUACK_HIP_TUNE=pipe=2,unroll=2" "QUACK_HIP_UNFUSED_ADAPTERS=1" "QUACK_HIP_TUNE=replicas=1" "QUACK_HIP_TUNE=replicas=2" \
+         "QUACK_HIP_TUNE=adapt_pd=3" "QUACK_HIP_TUNE=adapt_pd=4,adapt_u=1" "QUACK_HIP_TUNE=separate_count" \
+         "QUACK_HIP_NO_GROUP=1" "QUACK_HIP_TUNE=group=2" "QUACK_HIP_TUNE=small_ring" "QUACK_HIP_TUNE=ring_words=4096" "QUACK_HIP_NO_PAD=1" "QUACK_HIP_TUNE=pad_always" \
+         "QUACK_HIP_NO_W16=1" "QUACK_HIP_NO_SIDE=1" "QUACK_HIP_NO_TABLE32=1" "QUACK_HIP_TUNE=tile_overhead=0" "QUACK_HIP_TUNE=length_kernel"; do
   echo "== $e" | tee -a gpurun_out/stress.log
   env $e timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -rf -k "$K" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220 | tee -a gpurun_out/stress.log
 done
