@@ -1013,12 +1013,21 @@ def main():
     # field says what ran in front.
     first = None
     also_runs = {}
+    st = None
     if with_also:
         with phase("first_window"):
             first = job.run(args.steps, args.warmup)
         with phase("also_loops"):
             for nm in ALSO:
                 also_runs[nm] = also_jobs[nm].run(args.also_steps, args.also_warmup)
+    if rank == 0 and world == 1 and not args.no_steady:
+        # The same kernel once the part's power management has settled on it: 70 untimed + 100 timed passes.  A fresh process's
+        # launches run 514, 490, 498, 499 us, climb to 560 at launch 10 and decay to 487 +- 3 from launch 70 on
+        # (profiles/r03_first_launches.log).  Round 5 runs this loop IN FRONT of the contract's W + K steps: 750 launches of the
+        # other workloads did not always carry the headline kernel past its transient (three driver-shaped runs: 0.736, 0.729 and
+        # 0.683 against a steady 0.743-0.749; the transient follows THIS kernel's draw), 170 launches of the kernel itself do.
+        with phase("steady_state"):
+            st = job.run(100, 70)
     with phase("timed_loop"):
         res = job.run(args.steps, args.warmup, world=world, exchange=world > 1)
     per_rank = gather_ranks(ctx, res) if world > 1 else None
@@ -1051,10 +1060,10 @@ def main():
                 "what": "the same W + K steps as the first histogram launches of this process (a cold chip: the part's power "
                         "management settles over ~70 launches of this kernel); kept beside the headline, never `value`"}
             out["order"] = ("batches of every workload made up front; then, back to back: cfg2 W+K on the cold chip (roofline.first_window), the `also` "
-                            "workloads (%s: %d + %d launches each), cfg2 W+K again = `value` / `roofline` (the contract's %d untimed + %d timed "
-                            "steps, on a chip that has just run %d histogram launches), cfg2 70 + 100 (roofline.steady_state); CPU baselines, "
-                            "HBM-traffic passes and the other tiers afterwards" % (", ".join(ALSO), args.also_warmup, args.also_steps, args.warmup,
-                                                                                  args.steps, len(ALSO) * (args.also_warmup + args.also_steps)))
+                            "workloads (%s: %d + %d launches each), cfg2 70 + 100 (roofline.steady_state), cfg2 W+K again = `value` / `roofline` "
+                            "(the contract's %d untimed + %d timed steps, on a chip that has just run %d launches of the other workloads and 170 of "
+                            "this one); CPU baselines, HBM-traffic passes and the other tiers afterwards" % (
+                                ", ".join(ALSO), args.also_warmup, args.also_steps, args.warmup, args.steps, len(ALSO) * (args.also_warmup + args.also_steps)))
         if world > 1:
             import socket as _socket
             try:
@@ -1102,18 +1111,14 @@ def main():
             del job3
             torch.cuda.empty_cache()
 
-    if rank == 0 and world == 1 and not args.no_steady:
-        # Outside the contract's W + K steps, reported beside them and never as `value`: the same kernel once the part's power
-        # management has settled on it.  A fresh process's launches run 514, 490, 498, 499 us, climb to 560 at launch 10 and decay
-        # to 487 +- 3 from launch 70 on (profiles/r03_first_launches.log): `--warmup 5 --steps 20` times launches 6-25.
-        with phase("steady_state"):
-            st = job.run(100, 70)
+    if st is not None:
+        # (outside the contract's W + K steps, reported beside them and never as `value`)
         out["roofline"]["steady_state"] = {
             "kernel_ms": st["kernel_ms"], "kernel_ms_min": st["kernel_ms_min"], "kernel_ms_max": st["kernel_ms_max"],
             "frac": job.alg_bytes / (st["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": st["elapsed"] / st["steps"] * 1e3,
             "warmup": st["warmup"], "steps": st["steps"], "launches_timed": st["launches"],
-            "what": "a further loop on fresh accumulators, 70 untimed + 100 timed passes: the kernel after the power transient of its "
-                    "first ~70 launches; not the contract's figure (that is roofline.frac, from the W + K steps above)"}
+            "what": "a loop of 70 untimed + 100 timed passes on fresh accumulators, run in front of the contract's W + K steps: the kernel "
+                    "after the power transient of its first ~70 launches; not the contract's figure (that is roofline.frac)"}
     if rank == 0 and world == 1:
         if with_also:
             also = {}
