@@ -62,6 +62,9 @@ def hip_exp():
     parity tests that cross-check those geometries only; nothing of the product links it."""
     global _hip_exp
     if _hip_exp is None:
+        # the product's library first: it is loaded RTLD_GLOBAL, and with it the HIP runtime it links — a process whose FIRST HIP user is a
+        # library loaded RTLD_LOCAL ends up with two runtimes once torch brings its own copy ("No HIP GPUs are available" from torch)
+        hip()
         path = os.path.join(_HERE, "libquack_hip_exp.so")
         if not os.path.exists(path):
             raise NativeLibraryMissing("%s not built: run `make exp` at the repository root" % path)

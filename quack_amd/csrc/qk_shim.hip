@@ -763,6 +763,17 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
       if (rc) return rc;
     }
   }
+  // QK_BATCH_NEUTRAL_PADS on a device-resident batch: the promise is verified for the first batches of every accumulator (a producer
+  // that writes its pads wrongly does so from the start) and for every batch on request (QUACK_HIP_CHECK_PADS=1: tests,
+  // debugging a producer) — whichever kernel variant ends up running the batch: the promise is about the data
+  if (strided && (flags & QK_BATCH_NEUTRAL_PADS) && !no_group && (a->pads_checked < 2 || getenv("QUACK_HIP_CHECK_PADS"))) {
+    a->pads_checked++;
+    if ((rc = order_after_previous(a, st))) return rc;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + rem + 255) / 256, 4096);
+    hipLaunchKernelGGL(qk::pads_check_kernel, dim3(blocks), dim3(256), 0, st, d_seq, d_qual, d_len, n_reads + rem, stride, a->d_status);
+    QK_HIP(hipGetLastError());
+    a->status_armed = true;
+  }
   if (strided) {
     // The strided kernel variant exists for the planner's own geometry only.  Under a tuning override
     // (QUACK_HIP_THREADS / _UNROLL / _PIPE / _NO_ALIGN4 / _ADAPT_PD / _ADAPT_U, qk_accum_configure) the same
@@ -797,15 +808,6 @@ int enqueue_batch(qk_accum *a, const uint8_t *d_seq, const uint8_t *d_qual,
     }
   }
   if ((rc = order_after_previous(a, st))) return rc;
-  // the promise of a device-resident batch: verified for the first batches of every accumulator (a producer that writes its pads
-  // wrongly does so from the start) and for every batch on request (QUACK_HIP_CHECK_PADS=1: tests, debugging a producer)
-  if (strided && pl.neutral && (a->pads_checked < 2 || getenv("QUACK_HIP_CHECK_PADS"))) {
-    a->pads_checked++;
-    const unsigned blocks = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, 4096);
-    hipLaunchKernelGGL(qk::pads_check_kernel, dim3(blocks), dim3(256), 0, st, d_seq, d_qual, d_len, n_reads, stride, a->d_status);
-    QK_HIP(hipGetLastError());
-    a->status_armed = true;
-  }
   TimedLaunch tl{};
   // (events around a launch cost ~10 us of stream time: a caller that also measures its own wall
   // clock asks for every Nth batch only)

@@ -10,13 +10,17 @@ mkdir -p gpurun_out; : > gpurun_out/stress.log
 K="not cli and not launch_configurations and not pipelined and not tuning_overrides and not under_overrides"
 # (round 5: the experiment switches live in ONE variable, QUACK_HIP_TUNE, which only the -DQK_EXPERIMENT build parses — the Python
 #  mirror loads libquack_hip_exp.so whenever it is set; the QUACK_HIP_NO_* fallbacks are the product library's own)
+# (STRESS_FROM=n: start at the n-th setting — the whole matrix takes ~22 minutes, more than one gpurun call allows)
+I=0
 for e in "QUACK_HIP_TUNE=tile=64" "QUACK_HIP_TUNE=threads=512" "QUACK_HIP_TUNE=tile=128,threads=256,unroll=2" \
          "QUACK_HIP_TUNE=pipe=2,unroll=2" "QUACK_HIP_UNFUSED_ADAPTERS=1" "QUACK_HIP_TUNE=replicas=1" "QUACK_HIP_TUNE=replicas=2" \
          "QUACK_HIP_TUNE=adapt_pd=3" "QUACK_HIP_TUNE=adapt_pd=4,adapt_u=1" "QUACK_HIP_TUNE=separate_count" \
          "QUACK_HIP_NO_GROUP=1" "QUACK_HIP_TUNE=group=2" "QUACK_HIP_TUNE=small_ring" "QUACK_HIP_TUNE=ring_words=4096" "QUACK_HIP_NO_PAD=1" "QUACK_HIP_TUNE=pad_always" \
          "QUACK_HIP_NO_W16=1" "QUACK_HIP_NO_SIDE=1" "QUACK_HIP_NO_TABLE32=1" "QUACK_HIP_TUNE=tile_overhead=0" "QUACK_HIP_TUNE=length_kernel"; do
+  I=$((I+1)); [ $I -lt ${STRESS_FROM:-1} ] && continue; [ $I -gt ${STRESS_TO:-99} ] && continue
   echo "== $e" | tee -a gpurun_out/stress.log
   env $e timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -rf -k "$K" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220 | tee -a gpurun_out/stress.log
 done
-echo "== QUACK_HIP_BATCH_MB=1"
-QUACK_HIP_BATCH_MB=1 timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -rf -k "$K and not gapped and not promise" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220
+[ ${STRESS_TO:-99} -lt 99 ] && exit 0
+echo "== QUACK_HIP_BATCH_MB=1" | tee -a gpurun_out/stress.log
+QUACK_HIP_BATCH_MB=1 timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -rf -k "$K and not gapped and not promise" 2>&1 | grep -E "^FAILED|passed|failed" | cut -c1-220 | tee -a gpurun_out/stress.log
