@@ -229,7 +229,8 @@ int qk_accum_timing_read_batch(qk_accum *acc, double *hist_ms, double *batch_ms,
 /* Shortest and longest histogram-kernel launch among those (ms); both 0 when none was timed. */
 int qk_accum_timing_read_range(qk_accum *acc, double *hist_min_ms, double *hist_max_ms);
 
-/* ---- tuning knobs (env: QUACK_HIP_THREADS / _UNROLL / _TILE) ---------- */
+/* ---- launch geometry of the caller's choosing: the experiment build (libquack_hip_exp.so) has the kernel variants for it, the
+ * product library only those the planner itself picks (a launch under another geometry fails with QK_EINVAL there) ---------- */
 int qk_accum_configure(qk_accum *acc, int threads_per_wg, int unroll,
                        int tile_positions, int wgs_per_cu);
 
@@ -245,6 +246,12 @@ int qk_debug_plan(uint64_t n_reads, uint32_t max_len, int ragged, int adapters,
  * 150 bp at stride 152 -> two reads per row); out[8]: group, row positions, tile_pos, rows/iter, unroll, w16,
  * bucket_log2, LDS bytes. */
 int qk_debug_group(uint64_t n_reads, uint32_t read_len, uint32_t stride, uint32_t bucket_log2, uint64_t *out);
+/* Where the wide LDS layout of the fixed-length adapter kernel (16 positions per lane) puts its pieces for `chunks` 8-position
+ * chunks per row, `replicas` counter replicas, a bucket table of 2^bucket_log2 16-byte buckets (0: none) and a first-hit ring of
+ * fh_words words — the function the planner and the kernel share (qk::wide_plan).  out[8]: planes, bucket table at (dwords from
+ * LDS byte 0), ring at (0: in the unused column pairs of the last plane), dynamic LDS bytes (0: the shape does not fit), words
+ * of ring the last plane has room for, dwords of the small rows' gap that are taken, 0, 0. */
+int qk_debug_wide(uint32_t chunks, uint32_t replicas, uint32_t bucket_log2, uint32_t fh_words, uint64_t *out);
 /* Ablation builds of the histogram kernel (-DQK_ABLATION, tools/kbench only);
  * the product library only has mode 0 and rejects any other at launch. */
 int qk_debug_set_mode(int mode);

@@ -868,8 +868,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       const uint32_t g_first = g;
       for (uint32_t i = 0; i < 8u * K; ++i) {
         if (lane_on && cpos + i < row_len && g < GRP && pos < p.read_len) fixed_mask |= 1u << i;
-        if (lane_on && pos == 0u && g < GRP && cpos + i < row_len) {   // a read of the row starts in this lane's positions (one at most: a stride is >= 16)
-          owns_start = true;
+        if (pos == 0u && g < GRP && cpos + i < row_len) {   // a read of the row starts in this lane's positions (one at most: a stride is >= 16)
+          owns_start = lane_on;   // (a feeder lane loads that read's length like its original — the next lane asks for it — but counts nothing)
           len_g = g;
           straddles = g != g_first;
         }
@@ -1079,12 +1079,13 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       auto drain_candidates = [&]() {
         constexpr uint32_t NW = 8u * K;                 // windows per entry
         for (uint32_t i = lane_id; i < ((cand_n + 63u) & ~63u); i += 64u) {   // whole waves: bpermute below
-          uint32_t src, rel, hits, s_lo, s_hi, ez = 0;
+          uint32_t src, rel, hits, s_lo, s_hi, ez = 0, ew = 0;
           if constexpr (W16) {
             const uint4 e = cand_q16[i < cand_n ? i : 0u];
             ez = e.z;
             src = (e.z >> 16) & 63u;
-            rel = e.w;
+            rel = SV ? (e.w & 0xFFFFu) : e.w;
+            ew = e.w;
             // eight probe bits -> sixteen windows: probe i passed = windows 2i (the 9-mer is its suffix) and 2i + 1 (its prefix)
             uint32_t x = e.z >> 24;
             x = (x | (x << 4)) & 0x0F0Fu;
@@ -1143,7 +1144,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           if constexpr (SV && GROUPS) {   // (W16: the entry carries a length, see the push)
             elen = ez & 0x7FFFu;
             estr = (ez & 0x8000u) != 0;
-            len = estr ? lrow[rel * GRP + (g0 < GRP ? g0 : GRP - 1u)] : elen;
+            len = estr ? (ew >> 16) : elen;   // (a straddling lane: the read its first positions lie in is the previous lane's)
           }
           const uint32_t j0 = first_in_table(hits & window_mask((int32_t)pos0, len));
           const uint32_t found = j0 < NW ? pos0 + j0 : kNoHit;
@@ -1522,12 +1523,18 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
               if (cand_n + (uint32_t)__builtin_popcountll(pushers) > kCandCap16) drain_candidates();
 #endif
             }
+            // strided rows: a lane in whose positions a read starts holds THAT read's length; the read its first positions belong to
+            // is the previous lane's (a feeder lane stands in for the previous wave's last lane) — one DPP, so that the drain never
+            // loads a length (a global load there meant s_waitcnt vmcnt(0), i.e. waiting for the prefetched loads of the next step)
+            uint32_t plen = 0;
+            if constexpr (SV && W16) plen = from_prev_lane(nv[u]);
             if (hits) {
               const uint32_t at = cand_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushers, 0u));
               if constexpr (W16)   // (the words as they stand: own 16 codes; the previous lane's word, of which the drain reads bits 0-17)
                 // (strided rows: + the length this lane holds — of the read that starts in it, else of the read it lies in — and
                 //  whether its first positions belong to the read before that one: the drain then needs no load)
-                cand_q16[at] = make_uint4(ploU[u][1], prevU[u], hits | (lane_id << 16) | (SV ? (nv[u] & 0x7FFFu) | (straddles ? 0x8000u : 0u) : 0u), rl[u]);   // (a pushing lane's row is in the list: hits != 0 needs n != 0)
+                cand_q16[at] = make_uint4(ploU[u][1], prevU[u], hits | (lane_id << 16) | (SV ? (nv[u] & 0x7FFFu) | (straddles ? 0x8000u : 0u) : 0u),
+                                           rl[u] | (SV ? plen << 16 : 0u));   // (a pushing lane's row is in the list: hits != 0 needs n != 0; rel < 65536)
               else
                 cand_q[at] = make_uint2(ploU[u][0], prev2 | (hits << 2) | lane10 | (rl[u] << 16));
             }

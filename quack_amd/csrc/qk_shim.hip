@@ -1237,6 +1237,16 @@ int qk_debug_group(uint64_t n_reads, uint32_t read_len, uint32_t stride, uint32_
   return QK_OK;
 }
 
+int qk_debug_wide(uint32_t chunks, uint32_t replicas, uint32_t bucket_log2, uint32_t fh_words, uint64_t *out) {
+  if (!out || !chunks || !replicas) return fail(QK_EINVAL, "bad argument");
+  const qk::WidePlan w = qk::wide_plan(chunks, replicas, bucket_log2, fh_words);
+  out[0] = w.planes; out[1] = w.bucket_off; out[2] = w.ring_off; out[3] = w.bytes;
+  out[4] = qk::wide_spare_ring(4u * replicas * chunks);
+  out[5] = qk::kCandWords16 + 6u * 8u * chunks + 4u;
+  out[6] = out[7] = 0;
+  return QK_OK;
+}
+
 int qk_accum_create(qk_accum **out, int device, const uint32_t *kmer_bitset,
                     uint64_t max_len_hint) {
   if (!out) return fail(QK_EINVAL, "out is NULL");

@@ -131,3 +131,46 @@ def test_experiment_switches_live_in_the_experiment_build_only(monkeypatch):
                b"QUACK_HIP_UNFUSED_ADAPTERS", b"QUACK_HIP_TUNE"}   # (QUACK_HIP_TUNE: named in an error message, never read)
     extra = {n for n in names if n not in allowed and not n.startswith(b"QUACK_HIP_NO_")}
     assert not extra, extra
+
+
+def test_wide_lds_layout_pieces_never_overlap():
+    """Round 5: the fixed-length adapter kernel's LDS map (qk::wide_plan, shared by planner and kernel) — counter planes 64 KiB
+    apart, the 9-mer filter in the first gap, queue + letter rows + bucket table in the second, the first-hit ring in the unused
+    column pairs of the last plane or behind it.  For every shape: the pieces lie inside the dynamic segment asked for, inside
+    160 KiB, and do not overlap one another or a plane; a shape that does not fit says so (bytes == 0)."""
+    L.qk_debug_wide.argtypes = [ctypes.c_uint32] * 4 + [ctypes.POINTER(ctypes.c_uint64)]
+    PLANE, STRIDE, FILTER, REST, TOP, QUEUE = 8192, 16384, 8192, 24576, 32768, 4096     # dwords (qk_kernels.hip.h: kWide*)
+    fits = 0
+    for ch in range(2, 60, 2):
+        for rep in (1, 2, 3, 4, 6):
+            for blog in (0, 6, 8, 9, 10):
+                for fh in (2048, 4096, 8192, 16384):
+                    out = (ctypes.c_uint64 * 8)()
+                    assert L.qk_debug_wide(ch, rep, blog, fh, out) == 0
+                    planes, b_at, r_at, nbytes, spare, rest = (int(x) for x in out[:6])
+                    cols = 4 * rep * ch
+                    assert planes == (cols + 63) // 64
+                    if nbytes == 0:
+                        continue
+                    fits += 1
+                    assert planes <= 3 and nbytes <= 160 * 1024 and nbytes % 4 == 0
+                    end = nbytes // 4
+                    pieces = [(p * STRIDE, p * STRIDE + PLANE, "plane %d" % p) for p in range(planes)]
+                    pieces.append((FILTER, FILTER + 8192, "filter"))
+                    pieces.append((REST, REST + rest, "queue + rows"))
+                    assert rest >= QUEUE + 6 * 8 * ch
+                    if blog:
+                        pieces.append((b_at, b_at + (4 << blog), "buckets"))
+                    if r_at:
+                        pieces.append((r_at, r_at + fh, "ring"))
+                    else:
+                        assert fh <= spare and spare in (2048, 4096)
+                        # the ring's words: the last `spare / 256` column pairs of every row of the last plane — beyond the pairs in use
+                        free_pairs = planes * 32 - cols // 2
+                        assert spare // 256 <= free_pairs
+                    for a, e, what in pieces:
+                        assert 0 <= a < e <= end, (ch, rep, blog, fh, what, a, e, end)
+                    pieces.sort()
+                    for (a0, e0, w0), (a1, e1, w1) in zip(pieces, pieces[1:]):
+                        assert e0 <= a1, (ch, rep, blog, fh, w0, w1)
+    assert fits > 500
