@@ -92,6 +92,26 @@ int main(int argc, char **argv) {
            total, t_dec, total / t_dec / 1e6, t_res, total / t_res / 1e6, t_crc, total / t_crc / 1e6, t_nl, total / t_nl / 1e6,
            total / (t_dec + t_res + t_crc + t_nl) / 1e6, crc);
   }
+  /* what finding a block start costs a worker: from every 4 MiB of the compressed file on, like pinflate.c's slices */
+  {
+    qkh_inflate *z = malloc(sizeof *z);
+    double t0 = now();
+    unsigned found = 0, tried = 0;
+    uint64_t skipped = 0;
+    for (size_t at = (size_t)4 << 20; at + ((size_t)1 << 20) < (size_t)st.st_size; at += (size_t)4 << 20) {
+      const int64_t bit = qkh_inflate_find_block(data, st.st_size, (uint64_t)at * 8u, (uint64_t)st.st_size * 8u, z);
+      tried++;
+      if (bit >= 0) {
+        found++;
+        skipped += (uint64_t)bit - (uint64_t)at * 8u;
+      }
+    }
+    double dt = now() - t0;
+    if (tried)
+      printf("find_block   : %u of %u slice starts found in %.4f s = %.3f ms per slice, %.1f KiB of compressed data skipped on average\n", found, tried, dt,
+             dt / tried * 1e3, found ? skipped / 8.0 / found / 1024.0 : 0.0);
+    free(z);
+  }
   {
     gzFile g = gzopen(argv[1], "rb");
     gzbuffer(g, 1 << 20);
