@@ -476,6 +476,8 @@ __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
 // (the long-read build — ragged, W16, no adapter scan — is held to 120 VGPRs: four of its waves then leave 32 registers of
 // a SIMD free, which is what the waves of the NEXT batch's reach pre-pass (12-16 VGPRs, 2 KiB of LDS) need to run beside it
 // on the side stream instead of waiting for a workgroup to retire)
+__device__ __forceinline__ void wave_count_lds(uint32_t *cnt, uint32_t key, bool valid);   // (below: equal keys of a wave added up first)
+
 // ONE (round 5): the launch has one position tile and no work queue — block b owns read slice b, nothing else is compiled in.
 // The VALU-bound variant (fixed length + adapter scan + 16 positions per lane) runs at the register file's limit (128 VGPRs for
 // four waves per SIMD); with the three work-loop forms inlined side by side the one-tile form's step loop spilled its counter
@@ -656,10 +658,6 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   constexpr bool UNIFORM = FIXED && !SV;              // every read one length: lengths in closed form
   uint32_t events = 0, steps_v = 0;
   uint32_t fixed_mask = 0;   // FIXED: which of the lane's 8K positions are bases of a read (the same for every row): bit i = position cpos + i
-  // strided batches, 16 positions per lane (round 5): the read of a row whose length this lane loads with its bytes — the one that
-  // STARTS in the lane's positions (owns_start: the lane counts that read's length, quack.c:219), else the one its first position lies in
-  uint32_t len_g = 0;
-  bool owns_start = false, straddles = false;   // straddles: the lane's first position belongs to the read BEFORE the one that starts in it
 
   auto spill = [&]() {
 #pragma unroll
@@ -862,22 +860,45 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       fixed_mask = 0u;
       uint32_t g, pos;
       col_split(cpos, g, pos);
-      len_g = g < GRP ? g : GRP - 1u;
-      owns_start = false;
-      straddles = false;
-      const uint32_t g_first = g;
       for (uint32_t i = 0; i < 8u * K; ++i) {
         if (lane_on && cpos + i < row_len && g < GRP && pos < p.read_len) fixed_mask |= 1u << i;
-        if (pos == 0u && g < GRP && cpos + i < row_len) {   // a read of the row starts in this lane's positions (one at most: a stride is >= 16)
-          owns_start = lane_on;   // (a feeder lane loads that read's length like its original — the next lane asks for it — but counts nothing)
-          len_g = g;
-          straddles = g != g_first;
-        }
         ++pos;
         if (GROUPS && GRP > 1u && pos == GS) {
           pos = 0u;
           ++g;
         }
+      }
+    }
+
+    // Strided rows (16 positions per lane): length_count (quack.c:219), the kmers==NULL count (quack.c:215) and the check of
+    // device-side lengths[] for the slice's reads in ONE pass in front of the step loop — sixteen coalesced loads in flight per
+    // thread, equal lengths of a wave added up first (70 % of trimmed reads have one length).  Round 5's first build took the length
+    // with the read's bytes in every step, as the 8-position kernel does: one more load per lane and step, the count under nested
+    // exec masks, 98 VALU + 27 SALU per chunk against the padded twin's 82 + 19.
+    if constexpr (SV && W16) {
+      if (!p.lengths_done && slice_reads) {
+        const uint32_t total = slice_reads * GRP;
+        const uint32_t *lr = p.lengths + (size_t)r_begin * GRP;
+        const uint32_t lim = p.len_limit < TP ? p.len_limit : TP;
+        uint32_t mine = 0;
+        bool bad = false;
+        for (uint32_t base = 0; base < total; base += 16u * T) {   // (whole workgroup, whole waves: the counting uses ballots)
+          uint32_t v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const uint32_t i = base + (uint32_t)j * T + tid;
+            v[j] = i < total ? lr[i] : 0u;
+          }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const uint32_t len = v[j];
+            bad |= len > lim;
+            mine += (len > 10u && len <= lim) ? 1u : 0u;
+            wave_count_lds(lds_len, len - 1u, len != 0u && len <= lim);
+          }
+        }
+        if (bad) atomicOr(p.status, kStatusBadLength);   // (device-side lengths[] are only seen here)
+        n_gt10 += mine;
       }
     }
 
@@ -999,11 +1020,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       uint32_t fixed_off0[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) fixed_off0[u] = FIXED ? ((uint32_t)u * RW + ri) * p.stride + cposp : 0u;
-      // strided: lengths[] of the slice's reads, and the lane's place in a step's share of it
+      // strided: lengths[] of the slice's reads (the candidate check reads them)
       const uint32_t *lrow = SV ? p.lengths + (size_t)r_begin * GRP : nullptr;
-      uint32_t len_idx0[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) len_idx0[u] = ((uint32_t)u * RW + (ri < RW ? ri : 0u)) * GRP + len_g;
       auto issue = [&](uint32_t it, LoadT (&q)[U], LoadT (&s)[U], uint32_t (&nv)[U], uint32_t (&sk)[U],
                        uint32_t (&rl)[U]) __attribute__((always_inline)) {
         const uint32_t it_bytes = FIXED ? (uint32_t)__builtin_amdgcn_readfirstlane((int)it) * p.stride : 0u;
@@ -1034,7 +1052,9 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           // (8 positions per lane — the builds of rounds 2-4, one of them held to 64 VGPRs — keep their load under the exec mask: the
           //  unconditional form measured 8 % slower there, 0.512 -> 0.553 ms per 10M trimmed reads, for no reason the listing shows)
           if (SV) {
-            if constexpr (W16) nv[u] = lrow[in_list ? (uint32_t)__builtin_amdgcn_readfirstlane((int)it) * GRP + len_idx0[u] : 0u];
+            // (16 positions per lane: the lengths of a slice are counted in one pass in front of the step loop — process() — and the
+            //  candidate check loads the few it needs; the loop itself carries none)
+            if constexpr (W16) nv[u] = in_list ? 1u : 0u;
             else nv[u] = in_list ? p.lengths[(size_t)r_begin + rel] : 0u;
           }
           off = off < off_limit ? off : off_limit;   // stay inside the buffer (+ slack)
@@ -1079,13 +1099,11 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       auto drain_candidates = [&]() {
         constexpr uint32_t NW = 8u * K;                 // windows per entry
         for (uint32_t i = lane_id; i < ((cand_n + 63u) & ~63u); i += 64u) {   // whole waves: bpermute below
-          uint32_t src, rel, hits, s_lo, s_hi, ez = 0, ew = 0;
+          uint32_t src, rel, hits, s_lo, s_hi;
           if constexpr (W16) {
             const uint4 e = cand_q16[i < cand_n ? i : 0u];
-            ez = e.z;
             src = (e.z >> 16) & 63u;
-            rel = SV ? (e.w & 0xFFFFu) : e.w;
-            ew = e.w;
+            rel = e.w;
             // eight probe bits -> sixteen windows: probe i passed = windows 2i (the 9-mer is its suffix) and 2i + 1 (its prefix)
             uint32_t x = e.z >> 24;
             x = (x | (x << 4)) & 0x0F0Fu;
@@ -1139,13 +1157,9 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           // stride, to read g0 + 1 from its position 0 on (a stride is at least 16 positions: two reads at most)
           uint32_t g0, pos0;
           col_split(cp, g0, pos0);
-          uint32_t elen = 0;
-          bool estr = false;
-          if constexpr (SV && GROUPS) {   // (W16: the entry carries a length, see the push)
-            elen = ez & 0x7FFFu;
-            estr = (ez & 0x8000u) != 0;
-            len = estr ? (ew >> 16) : elen;   // (a straddling lane: the read its first positions lie in is the previous lane's)
-          }
+          // (strided rows: the lengths the check needs come from memory — a twentieth of the lanes ever gets here; carrying them
+          //  in the queue entry, by DPP from the lane that had loaded them, measured the same: 0.6218 / 0.6230 ms)
+          if constexpr (SV && GROUPS) len = lrow[rel * GRP + (g0 < GRP ? g0 : GRP - 1u)];
           const uint32_t j0 = first_in_table(hits & window_mask((int32_t)pos0, len));
           const uint32_t found = j0 < NW ? pos0 + j0 : kNoHit;
           uint32_t ring = rel;   // the read's word in the first-hit ring
@@ -1153,7 +1167,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             ring = rel * GRP + g0;
             rd = ring;           // (what tells two reads apart below)
             if (g0 + 1u < GRP && pos0 + NW > GS) {
-              const uint32_t len1 = SV ? (estr ? elen : 0u) : len;   // (a read that starts in the lane: the entry holds ITS length)
+              const uint32_t len1 = SV ? lrow[rel * GRP + g0 + 1u] : len;
               const uint32_t j1 = first_in_table(hits & window_mask((int32_t)pos0 - (int32_t)GS, len1));
               if (j1 < NW) __hip_atomic_fetch_min(fh_at((ring + 1u) & FHM), pos0 + j1 - GS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -1227,7 +1241,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           // length_count (quack.c:219) and the kmers==NULL count (quack.c:215) by the lane that owns the read's first
           // chunk: the length is in its register anyway.  (Late round 3; round 2 counted behind the step loop, a pass
           // of its own over lengths[], and gained nothing over the separate kernel: 24 us per 10M reads.)
-          if (!p.lengths_done && lane_on && (W16 ? (owns_start && row_in) : chl == 0u) && lenv != 0u) {
+          if (!W16 && !p.lengths_done && lane_on && chl == 0u && lenv != 0u) {
             const uint32_t len = lenv;
             if (len > p.len_limit || len > TP) atomicOr(p.status, kStatusBadLength);   // (device-side lengths[] are only seen here)
             else {
@@ -1523,18 +1537,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
               if (cand_n + (uint32_t)__builtin_popcountll(pushers) > kCandCap16) drain_candidates();
 #endif
             }
-            // strided rows: a lane in whose positions a read starts holds THAT read's length; the read its first positions belong to
-            // is the previous lane's (a feeder lane stands in for the previous wave's last lane) — one DPP, so that the drain never
-            // loads a length (a global load there meant s_waitcnt vmcnt(0), i.e. waiting for the prefetched loads of the next step)
-            uint32_t plen = 0;
-            if constexpr (SV && W16) plen = from_prev_lane(nv[u]);
             if (hits) {
               const uint32_t at = cand_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushers, 0u));
               if constexpr (W16)   // (the words as they stand: own 16 codes; the previous lane's word, of which the drain reads bits 0-17)
-                // (strided rows: + the length this lane holds — of the read that starts in it, else of the read it lies in — and
-                //  whether its first positions belong to the read before that one: the drain then needs no load)
-                cand_q16[at] = make_uint4(ploU[u][1], prevU[u], hits | (lane_id << 16) | (SV ? (nv[u] & 0x7FFFu) | (straddles ? 0x8000u : 0u) : 0u),
-                                           rl[u] | (SV ? plen << 16 : 0u));   // (a pushing lane's row is in the list: hits != 0 needs n != 0; rel < 65536)
+                cand_q16[at] = make_uint4(ploU[u][1], prevU[u], hits | (lane_id << 16), rl[u]);
               else
                 cand_q[at] = make_uint2(ploU[u][0], prev2 | (hits << 2) | lane10 | (rl[u] << 16));
             }
