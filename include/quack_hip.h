@@ -156,6 +156,10 @@ int qk_accum_submit_device_strided(qk_accum *acc, const void *d_seq, const void 
                                    const void *d_lengths /* u32[n_reads], or NULL: all max_len (padded fixed length) */, uint64_t n_reads,
                                    uint32_t stride, uint32_t max_len, void *hip_stream);
 int qk_accum_commit_strided(qk_accum *acc, uint64_t n_reads, uint32_t stride);
+/* When to prefer the strided layout over a packed ragged batch for short reads of mixed lengths (<= 352 bases): nearly always.  The
+ * strided kernels take n_reads x stride positions whatever the lengths; the packed ones pay per read and per base.  10M reads of
+ * U[30,150] bases (mean 60 % of the stride): strided 0.534 ms, packed 0.559; with the adapter table 0.596 against 0.914
+ * (profiles/r05_ragged_probe.log).  The host feed switches at a mean of 50 % of the longest read, 35 % with adapters. */
 /* QK_BATCH_NEUTRAL_PADS (round 4): the producer promises that the bytes behind every read's last base, up to the stride,
  * are 0xFF in both arrays.  Such a byte counts into a quality row the flush discards and matches none of T / C / G, so
  * the kernel runs without tail masks (a third of its instructions; 10M trimmed 150 bp reads 0.5300 -> 0.5178 ms); a

@@ -227,6 +227,13 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
   n_early_made = 0;
   uint32_t stride = 0;   /* != 0: short reads of nearly one length, laid out at a fixed stride */
   const int no_stride = getenv("QUACK_NO_STRIDE") != NULL;
+  /* Short reads of mixed lengths go out at a fixed stride (0xFF behind every read) rather than packed when their mean length is at
+   * least this many percent of the longest read.  Round 5 measured the two layouts on the same 10M reads (tools/ragged_probe.py,
+   * profiles/r05_ragged_probe.log): the strided kernels take n x stride positions whatever the lengths — U[30,150]: 0.534 ms,
+   * with adapters 0.596 — the packed (ragged) ones pay per read and per base — 0.559 / 0.914 ms at a fill of 0.60, 0.588 / 0.938 at
+   * 0.83: with the adapter scan the stride wins by a third at every fill that was tried.  (Rounds 2-4: 75 % either way.)  What it
+   * costs is PCIe traffic, of which the feed uses a sixth. */
+  const unsigned stride_in = bitset ? 35u : 50u, stride_out = bitset ? 30u : 45u;
   const int verbose = getenv("QUACK_VERBOSE") != NULL;
   const double t0 = now_s();
   double t_created, t_early, t_first = 0, t_parsed;
@@ -367,10 +374,10 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
         /* (a stride that one long read widened earlier comes back down once the batches are uniform again) */
         if (((uniform + 3u) & ~3u) < stride) stride = (uniform + 3u) & ~3u;
       } else if (n > 0 && !uniform) {
-        /* (no longer "nearly one length" — mean below 3/4 of the stride: the padding would be a third of the traffic) */
+        /* (the reads have become too short for the stride: see stride_in / stride_out) */
         uint64_t sum = 0;
         for (int64_t i = 0; i < n; i++) sum += lengths[i];
-        if (sum * 4 < (uint64_t)n * stride * 3) stride = 0;
+        if (sum * 100 < (uint64_t)n * stride * stride_out) stride = 0;
       }
       turn = (turn + 1) % n_devices;
       continue;
@@ -417,12 +424,12 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
       if (qk_accum_padded_stride(acc, uniform, &want) == 0 && want > uniform && want <= 512) stride = want;
     }
     if (n > 0 && !long_reads && !uniform && !no_stride) {
-      /* a ragged batch of short reads: is it "one length, some of them trimmed"?  (longest read <= 512:
-       * one position tile; mean >= 3/4 of it: the padding stays below a third of the traffic) */
+      /* a ragged batch of short reads: trimmed reads (longest read <= 512: one position tile; mean length at least stride_in
+       * percent of it) go out at a fixed stride from the next batch on */
       uint64_t longest = 0;
       for (int64_t i = 0; i < n; i++)
         if (offsets[i + 1] - offsets[i] > longest) longest = offsets[i + 1] - offsets[i];
-      if (longest >= 16 && longest <= 512 && total * 4 >= (uint64_t)n * longest * 3) stride = (uint32_t)((longest + 3) & ~3ull);
+      if (longest >= 16 && longest <= 512 && total * 100 >= (uint64_t)n * longest * stride_in) stride = (uint32_t)((longest + 3) & ~3ull);
     }
     turn = (turn + 1) % n_devices;
   }
