@@ -14,6 +14,7 @@
 #include <stdatomic.h>
 #include <sys/mman.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -63,12 +64,16 @@ int qkh_device_list(int *devs, int cap) {
 }
 
 /* ---- start-up overlap -------------------------------------------------------
- * Creating an accumulator (HIP runtime start-up, module load, device buffers: 0.2-0.3 s) and
+ * Creating an accumulator (HIP runtime start-up, module load, device buffers: 0.16-0.3 s) and
  * the first use of its pinned slots (0.03 s each) happen on a thread of their own, while the
  * tokenizer already parses the first reads into ordinary heap batches ("early" batches, 16 MiB
- * per array, at most 1 GiB in all); those go through the copying feed (qk_accum_submit*) once
- * the accumulators exist.  Everything after them uses the pinned slots directly. */
-enum { EARLY_BYTES = 16 << 20, EARLY_READS = 1 << 20, EARLY_MAX = 32 };
+ * per array).  Round 5: that thread, once the accumulators exist, also carries the early batches
+ * into the pinned slots and commits them — a queue between the two threads, its buffers reused
+ * — while the tokenizer goes on parsing; when the queue runs empty the tokenizer takes the pinned
+ * slots over and fills them directly.  (Rounds 3-4 parsed at most 32 early batches — a third of
+ * config 2's file: the tokenizer stood still whenever the runtime took longer than 0.12 s to
+ * come up — and submitted them before parsing on: 0.045 s more.) */
+enum { EARLY_BYTES = 16 << 20, EARLY_READS = 1 << 20, EARLY_MAX = 48 };   /* at most 1.5 GiB of reads + 0.4 GiB of offsets in flight */
 typedef struct {
   uint8_t *seq, *qual;
   uint64_t *off;
@@ -83,8 +88,17 @@ typedef struct {
   int n_devices, made, failed;
   const uint32_t *bitset;
   char err[300];
-  atomic_int done;
+  atomic_int done;          /* the accumulators exist (or could not be made: failed) */
+  /* the queue of early batches: the tokenizer publishes `head`, this thread `tail`; batch i lives in early[i % EARLY_MAX] */
+  early_batch *early;
+  atomic_uint head, tail;
+  atomic_int stop;          /* the tokenizer parses no more early batches */
+  int no_stride, turn, submitted;
+  uint32_t stride;          /* the padded stride the library asked for (0: none), for the batches behind the early ones */
+  double t_created, t_busy;
 } acc_creator;
+
+static int submit_early(acc_creator *c, early_batch *e);
 
 static void *acc_creator_main(void *p) {
   acc_creator *c = p;
@@ -109,7 +123,30 @@ static void *acc_creator_main(void *p) {
       break;
     }
   }
+  c->t_created = now_s();
   atomic_store(&c->done, 1);
+  /* the early batches, in the order they were parsed, until the tokenizer says there will be no more */
+  for (unsigned idle = 0;;) {
+    const unsigned t = atomic_load(&c->tail);
+    if (t != atomic_load(&c->head)) {
+      const double t0 = now_s();
+      if (!c->failed && submit_early(c, &c->early[t % EARLY_MAX])) {
+        snprintf(c->err, sizeof c->err, "%.290s", host_err);
+        c->failed = 1;   /* (the queue is still emptied: the tokenizer must not wait for a slot for ever) */
+      }
+      c->t_busy += now_s() - t0;
+      c->submitted++;
+      atomic_store(&c->tail, t + 1u);
+      idle = 0;
+      continue;
+    }
+    if (atomic_load(&c->stop) && t == atomic_load(&c->head)) break;   /* (head is final once stop is set) */
+    if (++idle < 200) sched_yield();
+    else {
+      struct timespec ts = {0, 50000};
+      nanosleep(&ts, NULL);
+    }
+  }
   return NULL;
 }
 
@@ -213,18 +250,45 @@ static void *early_reaper_main(void *p) {
   return NULL;
 }
 
+/* one early batch into the next accumulator's pinned slot (or, when the slots are smaller than an early batch, through the
+ * copying feed); runs on the creator thread */
+static int submit_early(acc_creator *c, early_batch *e) {
+  qk_accum *acc = c->accs[c->turn];
+  uint8_t *seq, *qual;
+  uint64_t *offsets, cap_bytes, cap_reads;
+  uint32_t pad = 0;
+  if (qk_accum_acquire(acc, &seq, &qual, &offsets, &cap_bytes, &cap_reads)) return host_fail("%s", qk_last_error());
+  if (e->uniform && !c->no_stride && (qk_accum_padded_stride(acc, e->uniform, &pad) || pad <= e->uniform)) pad = 0;
+  if (pad && (uint64_t)e->n * pad <= cap_bytes && (uint64_t)e->n <= cap_reads) {
+    /* uniform reads the library wants at a padded stride (see below): re-laid on the way into the slot */
+    parallel_pad(seq, qual, e->seq, e->qual, (uint64_t)e->n, e->uniform, pad);
+    if (qk_accum_commit_padded(acc, (uint64_t)e->n, e->uniform, pad)) return host_fail("%s", qk_last_error());
+    if (pad <= 512) c->stride = pad;   /* the batches behind the early ones are parsed into that layout directly */
+  } else if (e->total <= cap_bytes && (uint64_t)e->n <= cap_reads) {
+    copy_job jobs[3] = {{seq, e->seq, e->total}, {qual, e->qual, e->total},
+                        {offsets, e->off, e->uniform ? 0 : ((size_t)e->n + 1) * sizeof(uint64_t)}};
+    parallel_copy(jobs, 3);
+    if (qk_accum_commit(acc, (uint64_t)e->n, e->total, e->uniform == 0, e->uniform)) return host_fail("%s", qk_last_error());
+  } else if (qk_accum_commit(acc, 0, 0, 0, 0) ||   /* slots smaller than an early batch: the copying feed splits it */
+             (e->uniform ? qk_accum_submit_fixed(acc, e->seq, e->qual, e->uniform, (uint64_t)e->n)
+                         : qk_accum_submit(acc, e->seq, e->qual, e->off, (uint64_t)e->n))) {
+    return host_fail("%s", qk_last_error());
+  }
+  c->turn = (c->turn + 1) % c->n_devices;
+  return 0;
+}
+
 int qkh_accumulate_file(const char *path, const uint32_t *bitset,
                         const int *devices, int n_devices,
                         qk_base_info **bases_out, uint64_t *max_len,
                         uint64_t *n_reads) {
   qk_accum *accs[64];
   qkh_reader *rd = NULL;
-  int rc = -1, turn = 0, made = 0, long_reads = 0, n_early = 0, n_early_made;
+  int rc = -1, turn = 0, made = 0, long_reads = 0, n_early_made = 0, early_used = 0;
   early_batch early[EARLY_MAX];
   pthread_t reaper;
   int reaping = 0;
   memset(early, 0, sizeof early);
-  n_early_made = 0;
   uint32_t stride = 0;   /* != 0: short reads of nearly one length, laid out at a fixed stride */
   const int no_stride = getenv("QUACK_NO_STRIDE") != NULL;
   /* Short reads of mixed lengths go out at a fixed stride (0xFF behind every read) rather than packed when their mean length is at
@@ -236,7 +300,7 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
   const unsigned stride_in = bitset ? 35u : 50u, stride_out = bitset ? 30u : 45u;
   const int verbose = getenv("QUACK_VERBOSE") != NULL;
   const double t0 = now_s();
-  double t_created, t_early, t_first = 0, t_parsed;
+  double t_created, t_early, t_first = 0, t_parsed, t_copying = 0;
   *bases_out = NULL;
   *max_len = *n_reads = 0;
   if (n_devices < 1 || n_devices > 64) return host_fail("bad device count %d", n_devices);
@@ -256,83 +320,73 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
     cr.devices = devices;
     cr.n_devices = n_devices;
     cr.bitset = bitset;
+    cr.early = early;
+    cr.no_stride = no_stride;
     atomic_init(&cr.done, 0);
+    atomic_init(&cr.head, 0);
+    atomic_init(&cr.tail, 0);
+    atomic_init(&cr.stop, 0);
     /* (tests shrink the early batches to meet the "read longer than an early batch" case) */
     const size_t early_bytes = getenv("QUACK_EARLY_BYTES") ? (size_t)strtoull(getenv("QUACK_EARLY_BYTES"), NULL, 10) : (size_t)EARLY_BYTES;
+    unsigned head = 0;
+    int parse_failed = 0;
     threaded = !getenv("QUACK_NO_EARLY") && pthread_create(&th, NULL, acc_creator_main, &cr) == 0;
-    if (!threaded) acc_creator_main(&cr);
-    while (threaded && !atomic_load(&cr.done) && n_early < EARLY_MAX && !qkh_reader_done(rd)) {
-      early_batch *e = &early[n_early];
-      e->seq = early_alloc(early_bytes + QK_TAIL_SLACK);
-      e->qual = early_alloc(early_bytes + QK_TAIL_SLACK);
-      e->off = early_alloc(((size_t)EARLY_READS + 1) * sizeof(uint64_t));
-      if (!e->seq || !e->qual || !e->off) {
-        early_free(e);
-        break;   /* no memory to spare: wait for the accumulators instead */
+    if (!threaded) {
+      atomic_store(&cr.stop, 1);
+      acc_creator_main(&cr);
+    }
+    while (threaded && !qkh_reader_done(rd)) {
+      /* the accumulators exist and the other thread is down to the batch that was published a moment ago: from here on
+       * straight into the pinned slots (the join below waits for that last copy: ~1 ms) */
+      if (atomic_load(&cr.done) && (cr.failed || head - atomic_load(&cr.tail) <= 1u)) break;
+      if (head - atomic_load(&cr.tail) == (unsigned)EARLY_MAX) {   /* every buffer is waiting for its turn */
+        struct timespec ts = {0, 100000};
+        nanosleep(&ts, NULL);
+        continue;
+      }
+      early_batch *e = &early[head % EARLY_MAX];
+      if (!e->seq) {
+        e->seq = early_alloc(early_bytes + QK_TAIL_SLACK);
+        e->qual = early_alloc(early_bytes + QK_TAIL_SLACK);
+        e->off = early_alloc(((size_t)EARLY_READS + 1) * sizeof(uint64_t));
+        early_used++;
+        if (!e->seq || !e->qual || !e->off) {
+          early_free(e);
+          break;   /* no memory to spare: wait for the accumulators instead */
+        }
       }
       e->n = qkh_reader_fill(rd, e->seq, e->qual, e->off, early_bytes, EARLY_READS, &e->total, &e->uniform);
       if (e->n <= 0) {
-        const int64_t n = e->n;
-        early_free(e);
-        if (n == -4) break;   /* a read longer than an early batch: it stays parked for a pinned slot */
-        if (n == 0) continue;
-        pthread_join(th, NULL);
-        made = cr.made;
-        host_fail("%s: out of memory while parsing", path);
-        goto out;
+        if (e->n == -4) break;   /* a read longer than an early batch: it stays parked for a pinned slot */
+        if (e->n == 0) continue;
+        parse_failed = 1;
+        break;
       }
-      n_early++;
+      atomic_store(&cr.head, ++head);
     }
-    if (threaded) pthread_join(th, NULL);
+    if (threaded) {
+      atomic_store(&cr.stop, 1);
+      pthread_join(th, NULL);
+    }
     made = cr.made;
+    if (parse_failed) {
+      host_fail("%s: out of memory while parsing", path);
+      goto out;
+    }
     if (cr.failed) {
       host_fail("%s", cr.err);
       goto out;
     }
-  }
-  t_created = now_s();
-  for (int i = 0; i < n_early; i++) {
-    early_batch *e = &early[i];
-    qk_accum *acc = accs[turn];
-    uint8_t *seq, *qual;
-    uint64_t *offsets, cap_bytes, cap_reads;
-    if (qk_accum_acquire(acc, &seq, &qual, &offsets, &cap_bytes, &cap_reads)) {
-      host_fail("%s", qk_last_error());
-      goto out;
-    }
-    uint32_t pad = 0;
-    if (e->uniform && !no_stride && (qk_accum_padded_stride(acc, e->uniform, &pad) || pad <= e->uniform)) pad = 0;
-    if (pad && (uint64_t)e->n * pad <= cap_bytes && (uint64_t)e->n <= cap_reads) {
-      /* uniform reads the library wants at a padded stride (see below): re-laid on the way into the slot */
-      parallel_pad(seq, qual, e->seq, e->qual, (uint64_t)e->n, e->uniform, pad);
-      if (qk_accum_commit_padded(acc, (uint64_t)e->n, e->uniform, pad)) {
-        host_fail("%s", qk_last_error());
-        goto out;
-      }
-      if (pad <= 512) stride = pad;   /* the batches behind the early ones are parsed into that layout directly */
-    } else
-    if (e->total <= cap_bytes && (uint64_t)e->n <= cap_reads) {
-      copy_job jobs[3] = {{seq, e->seq, e->total}, {qual, e->qual, e->total},
-                          {offsets, e->off, e->uniform ? 0 : ((size_t)e->n + 1) * sizeof(uint64_t)}};
-      parallel_copy(jobs, 3);
-      if (qk_accum_commit(acc, (uint64_t)e->n, e->total, e->uniform == 0, e->uniform)) {
-        host_fail("%s", qk_last_error());
-        goto out;
-      }
-    } else if (qk_accum_commit(acc, 0, 0, 0, 0) ||   /* slots smaller than an early batch: the copying feed splits it */
-               (e->uniform ? qk_accum_submit_fixed(acc, e->seq, e->qual, e->uniform, (uint64_t)e->n)
-                           : qk_accum_submit(acc, e->seq, e->qual, e->off, (uint64_t)e->n))) {
-      host_fail("%s", qk_last_error());
-      goto out;
-    }
-    turn = (turn + 1) % n_devices;
+    turn = cr.turn;
+    stride = cr.stride;
+    n_early_made = cr.submitted;
+    t_created = cr.t_created;
+    t_copying = cr.t_busy;
   }
   /* unmapping 1 GiB costs ~0.1 s (TLB shootdowns across the producer threads): off the critical path */
-  if (n_early && pthread_create(&reaper, NULL, early_reaper_main, early) == 0) reaping = 1;
+  if (early_used && pthread_create(&reaper, NULL, early_reaper_main, early) == 0) reaping = 1;
   else early_reaper_main(early);
   t_early = now_s();
-  n_early_made = n_early;
-  n_early = 0;
   while (!qkh_reader_done(rd)) {
     uint8_t *seq, *qual;
     uint64_t *offsets, cap_bytes, cap_reads, total = 0;
@@ -461,15 +515,15 @@ int qkh_accumulate_file(const char *path, const uint32_t *bitset,
   }
   if (!t_first) t_first = t_parsed;
   if (verbose)
-    fprintf(stderr, "[quack] %s: accumulators %.3f s (%d early batches parsed meanwhile, submitted in %.3f s), first slot %.3f s, "
-            "parse+submit %.3f s, drain+finish %.3f s\n",
-            path, t_created - t0, n_early_made, t_early - t_created, t_first - t_early, t_parsed - t_first, now_s() - t_parsed);
+    fprintf(stderr, "[quack] %s: accumulators %.3f s; %d early batches (heap) until %.3f s, their copies + commits took %.3f s of the other thread; "
+            "first slot %.3f s, parse+submit %.3f s, drain+finish %.3f s\n",
+            path, t_created - t0, n_early_made, t_early - t0, t_copying, t_first - t_early, t_parsed - t_first, now_s() - t_parsed);
   rc = 0;
 out:
   {
     const double t_out = now_s();
     if (reaping) pthread_join(reaper, NULL);
-    else for (int i = 0; i < n_early; i++) early_free(&early[i]);
+    else early_reaper_main(early);
     /* the CLI exits right after printing: pinned memory, device buffers, streams and the HIP runtime
      * itself are left to the operating system (0.16 s of a 0.8 s run otherwise) */
     if (!(g_process_exits && rc == 0)) {

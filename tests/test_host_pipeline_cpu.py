@@ -171,7 +171,7 @@ def test_uniform_reads_of_an_odd_length_are_laid_out_at_a_padded_stride(quack_do
 
 def test_reads_parsed_while_the_accumulators_start_up(quack_double, tmp_path):
     """a slow HIP start-up (here: the double sleeps in qk_accum_create): the tokenizer fills heap batches
-    meanwhile and hands them to the copying feed; same SVG, also when the process exits without teardown
+    meanwhile, the thread that made the accumulators carries them into the slots while the tokenizer parses on (round 5); same SVG, also when the process exits without teardown
     (the CLI's default) and when a read is too long for an early batch"""
     g = np.random.default_rng(12)
     fq = tmp_path / "early.fq"
@@ -179,13 +179,17 @@ def test_reads_parsed_while_the_accumulators_start_up(quack_double, tmp_path):
     stats = lambda r: [int(t) for t in r.stderr.decode().split("[double]")[1].split() if t.isdigit()]
     want = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], QK_DOUBLE_VERBOSE="1")
     assert want.returncode == 0 and stats(want)[4] == 0
-    for extra in ({}, {"QUACK_DEVICES": "0,1,2"}):
+    # (QUACK_EARLY_BYTES=20000: ~170 early batches for a pool of 48 buffers — the tokenizer waits for the other thread and reuses them)
+    for extra in ({}, {"QUACK_DEVICES": "0,1,2"}, {"QUACK_EARLY_BYTES": "20000"}, {"QUACK_EARLY_BYTES": "20000", "QUACK_DEVICES": "0,1"}):
         got = run(quack_double, ["-u", str(fq), "-a", "adapters.fa"], early=True, QK_DOUBLE_CREATE_DELAY_MS="300",
                   QK_DOUBLE_VERBOSE="1", **extra)
         assert got.returncode == 0, got.stderr[-2000:]
         assert got.stdout == want.stdout
         copied = sum(int(l.split("copied")[1].split()[0]) for l in got.stderr.decode().splitlines() if l.startswith("[double]"))
-        assert copied >= 1, got.stderr               # early batches went through the copying feed
+        if "QUACK_EARLY_BYTES" in extra:             # (small early batches fit a slot of the double: copied into it and committed)
+            assert sum(int(l.split("commits")[1].split()[0]) for l in got.stderr.decode().splitlines() if l.startswith("[double]")) > 150, got.stderr
+        else:
+            assert copied >= 1, got.stderr           # early batches went through the copying feed
     env = dict(os.environ, QK_DOUBLE_CREATE_DELAY_MS="200")
     fast = subprocess.run([quack_double, "-u", str(fq), "-a", "adapters.fa"], capture_output=True,
                           cwd=os.path.join(cases.G, "inputs"), env=env, timeout=300)
@@ -201,7 +205,7 @@ def test_reads_parsed_while_the_accumulators_start_up(quack_double, tmp_path):
     b = run(quack_double, ["-u", str(big)])
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) > 1000
     import re
-    n_early = int(re.search(rb"\((\d+) early batches", a.stderr).group(1))
+    n_early = int(re.search(rb"(\d+) early batches", a.stderr).group(1))
     commits = int(a.stderr.decode().split("[double]")[1].split()[1])
     assert 1 <= n_early < commits, a.stderr            # early batches (they fit a slot here: copied into it), then the rest
 
