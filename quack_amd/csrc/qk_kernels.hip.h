@@ -327,6 +327,13 @@ inline size_t hist_lds_bytes(uint32_t ch, uint32_t replicas, bool adapt = false,
 // not G" indicators give them without an inversion), so its keys are the
 // reference's 10-mer indices (quack.c:150,208) xor 0xFFFFF.
 constexpr uint32_t kKmerMask = 0xFFFFFu;
+#ifdef QK_TIMING   /* experiment: where a workgroup's time goes (100 MHz stamps of thread 0; qk_shim prints them at finish) */
+__device__ unsigned long long qk_timing[1024 * 16];
+__device__ unsigned long long qk_wtime[1024 * 16];   /* per wave: when its step loop ended */
+#define QK_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024u) qk_timing[blockIdx.x * 16u + (i)] = wall_clock64(); } while (0)
+#else
+#define QK_MARK(i) do { } while (0)
+#endif
 // Exact membership in the bucket table: km' = km*mul mod 2^20 (a bijection for
 // odd mul); the top bucket_log2 bits pick a 16-byte bucket, the rest (< 2^15)
 // is stored with bit 15 set.  Empty slots are 0.
@@ -543,6 +550,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     }
   };
 
+  QK_MARK(0);
 #if defined(QK_ABL) && (QK_ABL & 1024)   /* experiment: what a launch costs without loading the adapter tables */
   if (false) {
 #else
@@ -631,6 +639,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   // SWAR byte counters for the 8 positions of a chunk: [0] positions 0-3, [1] 4-7 (W16: chunk k at [2k], [2k+1])
   uint32_t acc_v[2 * K] = {}, acc_t[2 * K] = {}, acc_c[2 * K] = {}, acc_g[2 * K] = {};
   uint32_t since_spill = 0;
+  uint32_t prio_step = 0;     // steps this wave has consumed (whose turn it is at which issue priority, see consume)
   // acc_t/c/g count the bytes that are NOT T/C/G (swar_ne, one instruction
   // shorter than the equality) and acc_v the events in which a byte was masked;
   // the spill takes events - count.  Masked bytes are "not equal" in every
@@ -717,6 +726,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       n_gt10 = 0;
     }
     __syncthreads();
+    QK_MARK(8);
     // fixed-length batches count unmasked: columns at and behind read_len hold the next read's bytes
     uint32_t pos_limit = (FIXED && p.read_len < p.table_len) ? p.read_len : p.table_len;
     if (NP && p.len_limit < pos_limit) pos_limit = p.len_limit;   // (columns behind the longest read hold pads and the next read's bytes)
@@ -744,6 +754,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         }
       }
     }
+    QK_MARK(9);
     for (uint32_t pp = tid; pp < span; pp += T) {
       uint32_t v = 0, t = 0, c = 0, g = 0;
       for (uint32_t gi = 0; gi < GRP; ++gi) {
@@ -774,6 +785,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         if (g) atomicAdd(row0 + 3u * TL, (unsigned long long)g);
       }
     }
+    QK_MARK(10);
     if (!UNIFORM && !p.lengths_done) {
       // reads that END in this tile (staged once per tile they reach, so each read counts exactly once)
       for (uint32_t pp = tid; pp < TP; pp += T) {
@@ -1005,6 +1017,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       // AHEAD (load_desc, right after the previous step's loads went out and
       // before its ds_adds), so that the LDS read does not queue behind a
       // step's 32 atomics when the next global loads want to start.
+      QK_MARK(2);
       uint2 de[U];
       auto load_desc = [&](uint32_t it) __attribute__((always_inline)) {
 #pragma unroll
@@ -1558,6 +1571,30 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           since_spill += U;
           if (since_spill + U > 255u) spill();   // byte counters hold <= 255
         }
+        // Issue priority by turns (round 5).  The four waves a SIMD holds do not advance alike: the arbiter takes the oldest ready
+        // wave first, and in-kernel time stamps (-DQK_TIMING, profiles/r05_phase_timing.log) showed the waves of a workgroup leaving
+        // the step loop in the order of their age, 10 us apart per age on config 2 (30 us from first to last: a tail in which every
+        // SIMD runs 3, 2, then 1 wave) and 1.5 us apart per fold interval with the adapter scan, where every fold point is a barrier
+        // that waits for the youngest.  s_setprio evens that out.  Without the adapter scan: the four priorities go round the
+        // four ages every 32 steps (config 2 -1.5 %, trimmed reads -3 %; a turn per step gains nothing there).  With it: the
+        // younger a wave, the larger its share of steps at priority 1 — age a in a of every 4 — which takes the skew between
+        // two fold points from 4.6 to 1.9 us and config 3 / 150 bp + adapters down 4-5 %.  (Measured in one process against
+        // the same build without it; other schedules — one-hot, two of four, the reverse order, longer periods — did less.)
+        if constexpr (FIXED && MODE == 0) {
+          const uint32_t age = threadIdx.x >> 8;   // waves w, w + 4, ... share a SIMD, in this order of age
+          if constexpr (ADAPT && W16) {
+            if (age + (prio_step & 3u) >= 4u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+          } else if ((prio_step & 31u) == 0u) {
+            switch (((prio_step >> 5) + age) & 3u) {
+              case 0: __builtin_amdgcn_s_setprio(0); break;
+              case 1: __builtin_amdgcn_s_setprio(1); break;
+              case 2: __builtin_amdgcn_s_setprio(2); break;
+              default: __builtin_amdgcn_s_setprio(3); break;
+            }
+          }
+          ++prio_step;
+        }
       };
       if constexpr (PD > 1) {
         // PD register sets: the loads of the next PD-1 steps are in flight
@@ -1611,6 +1648,10 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       if (ADAPT && cand_n) drain_candidates();   // the entries refer to this pass's read list
 #endif
     }
+    QK_MARK(3);
+#ifdef QK_TIMING
+    if ((threadIdx.x & 63u) == 0 && blockIdx.x < 1024u) qk_wtime[blockIdx.x * 16u + (threadIdx.x >> 6)] = wall_clock64();
+#endif
     if (fh_ring) {
       __syncthreads();   // every wave has drained its queue (above)
       fold_first_hits(slice_reads);
@@ -1635,6 +1676,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         }
       }
     }
+    QK_MARK(4);
     if (MODE == 0 || MODE == 3) spill();
     return slice_reads;
   };
@@ -1653,6 +1695,7 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       }
       zero_lds();
       __syncthreads();
+      QK_MARK(1);
       cur_tile = tile;
       reads_in_tile = 0;
     }
@@ -1765,7 +1808,12 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
 #if defined(QK_DUMMY_VALU) || defined(QK_ABL)
   if (keep == 0x12345679u) lds[1] = keep;
 #endif
+  QK_MARK(5);
   if (cur_tile != 0xFFFFFFFFu) flush(cur_tile);
+#ifdef QK_TIMING
+  __syncthreads();
+  QK_MARK(6);
+#endif
 }
 
 template <int T, int U, bool FIXED, int MODE, bool ADAPT = false, int PD = 1, bool AL = false, bool SV = false, bool W16 = false, bool NP = false, bool ONE = false>

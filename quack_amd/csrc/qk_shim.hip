@@ -1962,6 +1962,79 @@ int qk_accum_finish(qk_accum *a, qk_base_info *out, uint64_t cap_positions,
   if (!a) return fail(QK_EINVAL, "acc is NULL");
   int rc = settle(a);
   if (rc) return rc;
+#ifdef QK_TIMING   /* experiment: the phases of the last histogram launch, per workgroup (qk::qk_timing) */
+  if (out) {
+    static unsigned long long h[1024 * 16];
+    QK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(qk::qk_timing), sizeof h));
+    unsigned long long t_first = ~0ull, t_last = 0;
+    int nb = 0;
+    for (int b = 0; b < 1024; ++b)
+      if (h[b * 16]) {
+        ++nb;
+        t_first = std::min(t_first, h[b * 16]);
+        t_last = std::max(t_last, h[b * 16 + 6]);
+      }
+    fprintf(stderr, "[timing] %d workgroups, first start -> last end %.2f us\n", nb, (double)(t_last - t_first) / 100.0);
+    const char *names[6] = {"tables + LDS clear", "ring reset + prologue", "step loop", "fold", "spill", "flush"};
+    double start_mean = 0, start_max = 0;
+    for (int b = 0; b < 1024; ++b)
+      if (h[b * 16]) {
+        const double d = (double)(h[b * 16] - t_first) / 100.0;
+        start_mean += d / nb;
+        start_max = std::max(start_max, d);
+      }
+    fprintf(stderr, "[timing]   start after the first workgroup's: mean %.2f max %.2f us\n", start_mean, start_max);
+    {
+      static unsigned long long wt[1024 * 16];
+      QK_HIP(hipMemcpyFromSymbol(wt, HIP_SYMBOL(qk::qk_wtime), sizeof wt));
+      double skew = 0, skew_max = 0, tail = 0, w0 = 0;
+      for (int b = 0; b < 1024; ++b)
+        if (h[b * 16]) {
+          unsigned long long lo = ~0ull, hi = 0;
+          for (int w = 0; w < 16; ++w) lo = std::min(lo, wt[b * 16 + w]), hi = std::max(hi, wt[b * 16 + w]);
+          skew += (double)(hi - lo) / 100.0 / nb;
+          skew_max = std::max(skew_max, (double)(hi - lo) / 100.0);
+          tail += (double)((long long)(h[b * 16 + 6] - hi)) / 100.0 / nb;
+          w0 += (double)((long long)(wt[b * 16] - lo)) / 100.0 / nb;
+        }
+      {
+        double per[16] = {0};
+        for (int b = 0; b < 1024; ++b)
+          if (h[b * 16]) {
+            unsigned long long lo = ~0ull;
+            for (int w = 0; w < 16; ++w) lo = std::min(lo, wt[b * 16 + w]);
+            for (int w = 0; w < 16; ++w) per[w] += (double)(wt[b * 16 + w] - lo) / 100.0 / nb;
+          }
+        fprintf(stderr, "[timing]   wave w leaves the loop this long after the workgroup's first (mean, us):");
+        for (int w = 0; w < 16; ++w) fprintf(stderr, " %.1f", per[w]);
+        fprintf(stderr, "\n");
+      }
+      fprintf(stderr, "[timing]   waves of a workgroup leave the step loop %.2f us apart (mean; max %.2f; wave 0 %.2f after the first); "
+              "last wave out -> workgroup done: %.2f us\n", skew, skew_max, w0, tail);
+    }
+    {
+      const char *fn[4] = {"flush: wait for the waves", "flush: quality rows", "flush: content rows", "flush: the rest + atomics done"};
+      const int a[4] = {5, 8, 9, 10}, e[4] = {8, 9, 10, 6};
+      for (int i = 0; i < 4; ++i) {
+        double mean = 0;
+        for (int b = 0; b < 1024; ++b)
+          if (h[b * 16]) mean += (double)((long long)(h[b * 16 + e[i]] - h[b * 16 + a[i]])) / 100.0 / nb;
+        fprintf(stderr, "[timing]   %-32s mean %.2f us\n", fn[i], mean);
+      }
+    }
+    for (int i = 0; i < 6; ++i) {
+      double mean = 0, mx = 0, mn = 1e30;
+      for (int b = 0; b < 1024; ++b)
+        if (h[b * 16]) {
+          const double d = (double)((long long)(h[b * 16 + i + 1] - h[b * 16 + i])) / 100.0;
+          mean += d / nb;
+          mx = std::max(mx, d);
+          mn = std::min(mn, d);
+        }
+      fprintf(stderr, "[timing]   %-22s mean %.2f min %.2f max %.2f us\n", names[i], mean, mn, mx);
+    }
+  }
+#endif
   if (max_len) *max_len = a->max_len;
   if (n_reads) *n_reads = a->n_reads;
   if (!out) return QK_OK;
