@@ -668,7 +668,44 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   uint32_t events = 0, steps_v = 0;
   uint32_t fixed_mask = 0;   // FIXED: which of the lane's 8K positions are bases of a read (the same for every row): bit i = position cpos + i
 
+  uint32_t cur_tile = 0xFFFFFFFFu, reads_in_tile = 0;   // (work loop below) the tile whose counters the LDS holds; reads (rows) since its last flush
   auto spill = [&]() {
+    if constexpr (FAST_FIXED) {
+      // No tail masks (round 5: the short form).  `valid` needs no counter at all — every read of the tile covers every position
+      // that is flushed (UNIFORM: rows since the last flush x reads per row; NP: from the lengths) —, T and C share one word
+      // (16 bits each: a workgroup sees at most 65,535 reads between two flushes, kMaxReadsPerSlice) and nothing is skipped: two
+      // LDS adds per position instead of four under four branches.  A spill was 3.5 us per wave of the adapter kernel and the
+      // four waves of a SIMD take turns at the LDS: 10 us at the end of a launch, and again every 255 steps (-DQK_TIMING).
+      // Lanes that own no position of a read (feeders, the lanes behind a row) add nothing; positions of a lane that lie behind
+      // its read count into columns nobody flushes.
+      if (fixed_mask != 0u) {
+#pragma unroll
+        for (int d = 0; d < 2 * K; ++d) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const uint32_t off = (8u * chk[d >> 1] + 4u * (d & 1) + b) * 4u;
+            uint32_t t = (acc_t[d] >> (8 * b)) & 0xFFu;
+            uint32_t c = (acc_c[d] >> (8 * b)) & 0xFFu;
+            uint32_t g = (acc_g[d] >> (8 * b)) & 0xFFu;
+            if constexpr (LUTV) {   // acc_t / acc_c count the T / C bytes themselves, acc_g the bytes that are A-like or C
+              g = steps_v - g - t;
+            } else {
+              t = steps_v - t;
+              c = steps_v - c;
+              g = steps_v - g;
+            }
+            lds_add(lds_base, off + 4u * TP, t | (c << 16));
+            lds_add(lds_base, off + 12u * TP, g);
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 2 * K; ++d) acc_v[d] = acc_t[d] = acc_c[d] = acc_g[d] = 0;
+      since_spill = 0;
+      events = 0;
+      steps_v = 0;
+      return;
+    }
 #pragma unroll
     for (int d = 0; d < 2 * K; ++d) {
 #pragma unroll
@@ -759,11 +796,18 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       uint32_t v = 0, t = 0, c = 0, g = 0;
       for (uint32_t gi = 0; gi < GRP; ++gi) {
         const uint32_t col = pp + gi * GS;
-        v += lds_base[col];
-        t += lds_base[TP + col];
-        c += lds_base[2u * TP + col];
+        if constexpr (FAST_FIXED) {   // (see spill: T | C << 16 in one word, no `valid` row)
+          const uint32_t tc = lds_base[TP + col];
+          t += tc & 0xFFFFu;
+          c += tc >> 16;
+        } else {
+          v += lds_base[col];
+          t += lds_base[TP + col];
+          c += lds_base[2u * TP + col];
+        }
         g += lds_base[3u * TP + col];
       }
+      if constexpr (UNIFORM) v = reads_in_tile * GRP;   // every read of the tile has every position below read_len
       const uint32_t pos = P0 + pp;
       if (NP) {   // reads (of this workgroup, since its last flush) longer than the position: from the lengths counted in the loop
         v = 0;
@@ -1682,7 +1726,6 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
   };
 
   // ---- work loop
-  uint32_t cur_tile = 0xFFFFFFFFu, reads_in_tile = 0;
   auto tile_reads = [&](uint32_t tile) -> uint64_t { return (!FIXED && p.reach) ? p.reach[tile] : p.n_reads; };
   auto run_item = [&](uint32_t tile, uint64_t rb, uint64_t re_in) {
     const uint64_t nt = tile_reads(tile);
