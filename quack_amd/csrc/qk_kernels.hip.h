@@ -772,22 +772,46 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
     const uint32_t span = (GROUPS && GRP > 1u) ? p.read_len : TP;
     // (every workgroup starting at another row — same-address queueing at the L2 — was measured again in round 4, also on 0.2 ms
     // launches of 36 bp reads where the workgroups do finish in step: nothing, 0.1864 / 0.1847 ms)
-    for (uint32_t row = 33u + wave; row <= 123u; row += T / 64) {  // quack.c:203: bin = byte - 33
+    // (round 5: a lane's position owns the same words in every row, so the rows of a wave go innermost — one address per
+    //  (read of the row, replica), six independent LDS reads behind it, one wait — where the first form walked row by row with an
+    //  address computation and a waited-for read per word: 4.2-6.7 us of every launch by the in-kernel stamps)
+    constexpr uint32_t kRowsPerWave = (91u + T / 64u - 1u) / (T / 64u);   // quality rows 33..123 (quack.c:203: bin = byte - 33)
+    constexpr uint32_t kRowsAtOnce = FIXED ? 3u : 1u;   // (registers: six rows at once pushed half of the variants into scratch; the ragged kernels, which flush inside their work loop, keep one)
+    const uint32_t row_words = WIDE ? 64u : 32u;
+    const uint32_t *hist = WIDE ? lds_raw : lds;
+#pragma unroll 1
+    for (uint32_t k0 = 0; k0 < kRowsPerWave; k0 += kRowsAtOnce) {
+#pragma unroll 1
       for (uint32_t pp = lane; pp < span; pp += 64u) {
-        uint32_t c = 0;
+        uint32_t cnt[kRowsAtOnce];
+#pragma unroll
+        for (uint32_t k = 0; k < kRowsAtOnce; ++k) cnt[k] = 0;
         for (uint32_t gi = 0; gi < GRP; ++gi) {
           const uint32_t col = pp + gi * GS;
           const uint32_t c8 = col >> 3, j = col & 7u;
           for (uint32_t rep = 0; rep < R; ++rep) {
             const uint32_t hs = rep * 4u + (j & 3u);   // the set
-            const uint32_t w = WIDE ? lds_raw[qhist_index_wide(row, hs * (CH / 2u) + (c8 >> 1), c8 & 1u)] : lds[qhist_index(row, hs * CH + lds_col(c8))];
-            c += (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
+            const uint32_t at = WIDE ? qhist_index_wide(0u, hs * (CH / 2u) + (c8 >> 1), c8 & 1u) : qhist_index(0u, hs * CH + lds_col(c8));
+            uint32_t w[kRowsAtOnce];
+#pragma unroll
+            for (uint32_t k = 0; k < kRowsAtOnce; ++k) {   // (a last row past 123: read row 127, unused)
+              const uint32_t row = 33u + wave + (k0 + k) * (T / 64u);
+              w[k] = hist[at + (row < 127u ? row : 127u) * row_words];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kRowsAtOnce; ++k) cnt[k] += (j >> 2) ? (w[k] >> 16) : (w[k] & 0xFFFFu);
           }
         }
         const uint32_t pos = P0 + pp;
-        if (c != 0 && pos < pos_limit) {
-          if (p.table32) atomicAdd(&p.table32[(uint64_t)(row - 33u) * TL + pos], c);
-          else atomicAdd(&p.table[(uint64_t)(row - 33u) * TL + pos], (unsigned long long)c);
+        if (pos < pos_limit) {
+#pragma unroll
+          for (uint32_t k = 0; k < kRowsAtOnce; ++k) {
+            const uint32_t row = 33u + wave + (k0 + k) * (T / 64u);
+            if (row <= 123u && cnt[k] != 0) {
+              if (p.table32) atomicAdd(&p.table32[(uint64_t)(row - 33u) * TL + pos], cnt[k]);
+              else atomicAdd(&p.table[(uint64_t)(row - 33u) * TL + pos], (unsigned long long)cnt[k]);
+            }
+          }
         }
       }
     }
