@@ -962,6 +962,11 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         const uint32_t lim = p.len_limit < TP ? p.len_limit : TP;
         uint32_t mine = 0;
         bool bad = false;
+        // (the batch's longest length — what the untrimmed reads have — is counted by one ballot per load and added once per wave;
+        //  the other lengths go to the LDS lane by lane unless a wave meets many of them, which the leader loop of wave_count_lds
+        //  is for.  The in-kernel stamps had this pass at 22 us per launch of 10M reads with the leader loop on everything.)
+        const uint32_t hot = lim;
+        uint32_t hot_n = 0;
         for (uint32_t base = 0; base < total; base += 16u * T) {   // (whole workgroup, whole waves: the counting uses ballots)
           uint32_t v[16];
 #pragma unroll
@@ -974,9 +979,14 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
             const uint32_t len = v[j];
             bad |= len > lim;
             mine += (len > 10u && len <= lim) ? 1u : 0u;
-            wave_count_lds(lds_len, len - 1u, len != 0u && len <= lim);
+            const bool is_hot = len == hot && len != 0u;
+            hot_n += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(is_hot));
+            const bool rest = len != 0u && len < hot;
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(rest)) > 24) wave_count_lds(lds_len, len - 1u, rest);
+            else if (rest) atomicAdd(&lds_len[len - 1u], 1u);
           }
         }
+        if ((tid & 63u) == 0u && hot_n) atomicAdd(&lds_len[hot - 1u], hot_n);
         if (bad) atomicOr(p.status, kStatusBadLength);   // (device-side lengths[] are only seen here)
         n_gt10 += mine;
       }
