@@ -1248,20 +1248,40 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
           // stride, to read g0 + 1 from its position 0 on (a stride is at least 16 positions: two reads at most)
           uint32_t g0, pos0;
           col_split(cp, g0, pos0);
-          // (strided rows: the lengths the check needs come from memory — a twentieth of the lanes ever gets here; carrying them
-          //  in the queue entry, by DPP from the lane that had loaded them, measured the same: 0.6218 / 0.6230 ms)
-          if constexpr (SV && GROUPS) len = lrow[rel * GRP + (g0 < GRP ? g0 : GRP - 1u)];
+          uint32_t found, ring = rel;   // (ring: the read's word in the first-hit ring)
+          if constexpr (SV && GROUPS) {
+            // Strided rows: the lengths the check needs come from memory — a twentieth of the lanes ever gets here.  Both are
+            // requested first and looked at last: the look-ups need only the lower end of a read's windows (e >= 9), and since
+            // it is the FIRST window in the table that counts, the upper end (e <= l - 2) is one comparison behind them.
+            // (Loaded where they were used, every check waited for memory — with vmcnt(0), i.e. for the next step's bytes as
+            // well: 3 % of the kernel; carried in the queue entry by DPP from a lane that had loaded them: the same.)
+            const uint32_t gi0 = g0 < GRP ? g0 : GRP - 1u, gi1 = gi0 + 1u < GRP ? gi0 + 1u : gi0;
+            const uint32_t la = lrow[rel * GRP + gi0], lb = lrow[rel * GRP + gi1];
+            auto from_nine = [&](int32_t base) -> uint32_t {
+              int32_t lo = 9 - base;
+              lo = lo < 0 ? 0 : lo;
+              return lo >= (int32_t)NW ? 0u : ((((1u << NW) - 1u) >> (uint32_t)lo) << (uint32_t)lo);
+            };
+            const uint32_t j0 = first_in_table(hits & from_nine((int32_t)pos0));
+            uint32_t j1 = NW;
+            const bool second = GRP > 1u && g0 + 1u < GRP && pos0 + NW > GS;
+            if (second) j1 = first_in_table(hits & from_nine((int32_t)pos0 - (int32_t)GS));
+            found = (j0 < NW && pos0 + j0 + 1u < la) ? pos0 + j0 : kNoHit;
+            ring = rel * GRP + g0;
+            if (GRP > 1u) rd = ring;           // (what tells two reads apart below)
+            if (second && j1 < NW && pos0 + j1 - GS + 1u < lb)
+              __hip_atomic_fetch_min(fh_at((ring + 1u) & FHM), pos0 + j1 - GS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
           const uint32_t j0 = first_in_table(hits & window_mask((int32_t)pos0, len));
-          const uint32_t found = j0 < NW ? pos0 + j0 : kNoHit;
-          uint32_t ring = rel;   // the read's word in the first-hit ring
+          found = j0 < NW ? pos0 + j0 : kNoHit;
           if (GROUPS && GRP > 1u) {
             ring = rel * GRP + g0;
             rd = ring;           // (what tells two reads apart below)
             if (g0 + 1u < GRP && pos0 + NW > GS) {
-              const uint32_t len1 = SV ? lrow[rel * GRP + g0 + 1u] : len;
-              const uint32_t j1 = first_in_table(hits & window_mask((int32_t)pos0 - (int32_t)GS, len1));
+              const uint32_t j1 = first_in_table(hits & window_mask((int32_t)pos0 - (int32_t)GS, len));
               if (j1 < NW) __hip_atomic_fetch_min(fh_at((ring + 1u) & FHM), pos0 + j1 - GS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+          }
           }
           // An adapter covers several chunks of its read, and their entries sit next to each other in
           // the queue in ascending position (lane order of one step): only the first of a run of
