@@ -1678,9 +1678,12 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
         // younger a wave, the larger its share of steps at priority 1 — age a in a of every 4 — which takes the skew between
         // two fold points from 4.6 to 1.9 us and config 3 / 150 bp + adapters down 4-5 %.  (Measured in one process against
         // the same build without it; other schedules — one-hot, two of four, the reverse order, longer periods — did less.)
-        if constexpr (FIXED && MODE == 0) {
+        // (ragged batches — passes of staged reads with a barrier between them — take the second schedule too: 10M packed reads of
+        //  120-150 bases 0.612 -> 0.583 ms; the long-read kernel of config 5 measures the same either way — and so do the adapter
+        //  kernels of 8 positions per lane: packed 150 bp reads + adapters 0.698 -> 0.649)
+        if constexpr (MODE == 0) {
           const uint32_t age = threadIdx.x >> 8;   // waves w, w + 4, ... share a SIMD, in this order of age
-          if constexpr (ADAPT && W16) {
+          if constexpr (ADAPT || !FIXED) {
             if (age + (prio_step & 3u) >= 4u) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
           } else if ((prio_step & 31u) == 0u) {
