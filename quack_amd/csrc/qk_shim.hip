@@ -1984,6 +1984,22 @@ int qk_accum_finish(qk_accum *a, qk_base_info *out, uint64_t cap_positions,
         start_max = std::max(start_max, d);
       }
     fprintf(stderr, "[timing]   start after the first workgroup's: mean %.2f max %.2f us\n", start_mean, start_max);
+    {   // when the workgroups end, and whether that goes with the XCD (workgroup b runs on XCD b % 8)
+      double end_mean = 0, end_min = 1e30, end_max = 0, by_xcd[8] = {0};
+      int n_xcd[8] = {0};
+      for (int b = 0; b < 1024; ++b)
+        if (h[b * 16]) {
+          const double d = (double)(h[b * 16 + 6] - t_first) / 100.0;
+          end_mean += d / nb;
+          end_min = std::min(end_min, d);
+          end_max = std::max(end_max, d);
+          by_xcd[b & 7] += d;
+          n_xcd[b & 7]++;
+        }
+      fprintf(stderr, "[timing]   workgroups end (after the first start): mean %.2f min %.2f max %.2f us; by XCD:", end_mean, end_min, end_max);
+      for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", n_xcd[x] ? by_xcd[x] / n_xcd[x] : 0.0);
+      fprintf(stderr, "\n");
+    }
     {
       static unsigned long long wt[1024 * 16];
       QK_HIP(hipMemcpyFromSymbol(wt, HIP_SYMBOL(qk::qk_wtime), sizeof wt));
