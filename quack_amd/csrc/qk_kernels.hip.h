@@ -712,7 +712,6 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       for (int b = 0; b < 4; ++b) {
         const uint32_t off = (8u * chk[d >> 1] + 4u * (d & 1) + b) * 4u;
         uint32_t v = events - ((acc_v[d] >> (8 * b)) & 0xFFu);   // acc_v counts the events in which the byte was masked
-        if (FAST_FIXED) v = ((fixed_mask >> (4 * d + b)) & 1u) ? steps_v : 0u;
         if (v == 0) continue;  // nothing valid => no T/C/G either
         lds_add(lds_base, off, v);
         // (T and C in one word, 16 bits each — a workgroup sees at most 65,535 reads between two flushes — and no test for zero:
@@ -1741,6 +1740,8 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
 #ifdef QK_TIMING
     if ((threadIdx.x & 63u) == 0 && blockIdx.x < 1024u) qk_wtime[blockIdx.x * 16u + (threadIdx.x >> 6)] = wall_clock64();
 #endif
+    // (the letter counters go to the LDS before the workgroup meets: a wave that left the loop early spills while the others still run)
+    if (MODE == 0 || MODE == 3) spill();
     if (fh_ring) {
       __syncthreads();   // every wave has drained its queue (above)
       fold_first_hits(slice_reads);
@@ -1766,7 +1767,6 @@ __device__ __forceinline__ void hist_body(const HistParams &p) {
       }
     }
     QK_MARK(4);
-    if (MODE == 0 || MODE == 3) spill();
     return slice_reads;
   };
 
