@@ -74,6 +74,35 @@ def test_17M_identical_reads(adapters, table32, monkeypatch):
     np.testing.assert_array_equal(sd.bases, m * closed_form(n, L, Q("I"), 3, adapters))
 
 
+@pytest.mark.parametrize("adapters", [False, True], ids=["plain", "adapters"])
+def test_17M_reads_of_T_and_of_C(adapters):
+    """Round 5: the letter counters of T and C share one LDS word, 16 bits each (hist_body: spill).  17M reads of nothing but T,
+    then of nothing but C: every workgroup takes a column's T count to its limit between two flushes — a carry would show up in
+    C — and the other way round; fixed length, padded to 152 with the adapter tables loaded (no 10-mer of T or C is an adapter's)"""
+    import synth
+    n, L = 17_000_000, 150
+    ads = synth.synthetic_adapters()
+    k = ob.kmers_from_seqs(ads)
+    assert k[int("1" * 10, 4)] == 0 and k[int("2" * 10, 4)] == 0     # TTTTTTTTTT, CCCCCCCCCC (A,T,C,G = 0,1,2,3: quack.c:150)
+    want = np.zeros((L, 97), np.uint64)
+    with quack_amd.Accumulator(0, ob.kmers_to_bitset(k) if adapters else None, max_len_hint=L) as acc:
+        for letter, row in ((b"T", 1), (b"C", 2)):
+            if adapters:
+                seq = torch.full((n * 152 + 16,), letter[0], dtype=torch.uint8, device="cuda")
+                ql = torch.full((n * 152 + 16,), ord("I"), dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                acc.submit_device_padded(seq, ql, n, L, 152)
+            else:
+                seq, ql = constant_batch(n, L, base=letter)
+                acc.submit_device(seq, ql, None, n, n * L, L)
+            acc.sync()
+            del seq, ql
+            want += closed_form(n, L, Q("I"), row, adapters)
+        sd = acc.finish()
+    assert sd.number_of_sequences == 2 * n
+    np.testing.assert_array_equal(sd.bases, want)
+
+
 def test_poly_g_tails_10M():
     """NovaSeq's signature: a random prefix, then G at Q2 ('#') to the end of the read"""
     n, L = 10_000_000, 150
