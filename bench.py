@@ -785,7 +785,67 @@ def _e2e_entry(ctx, made, name, lo, hi, adapters_fa=None, splice=0.0, runs=3, ma
                         pass
 
 
-def tier_end_to_end(ctx, n_reads, left=lambda: 1e9):
+class E2eFiles:
+    """the .fq.gz files of the end-to-end tier, made by a thread of their own (tools/gen_fastq processes): started in front of the
+    HBM-traffic passes — children that have the GPU to themselves and little use for the host's cores — so that the tier finds
+    them ready (round 4 made them inside the tier: 38 s of a 128 s run; round 5 at first likewise, 63 s of 160)"""
+
+    def __init__(self, np, n_reads, scale, left):
+        import shutil
+        import tempfile
+        import threading
+        self.skipped = None
+        self.made, self.handles, self.note = {}, {}, ""
+        self.d = tempfile.mkdtemp(prefix="quack_e2e_")
+        # the adapter FASTA of config 3: the bench's 24 synthetic adapters
+        _, ads = synthetic_adapter_bits(np)
+        self.fa = os.path.join(self.d, "adapters.fa")
+        with open(self.fa, "w") as f:
+            for i, a in enumerate(ads):
+                f.write(">adapter%d\n%s\n" % (i, bytes(a).decode()))
+        n2, n5 = int(10_000_000 * scale), int(143_000 * scale)
+        need = (n2 * 150 * 2.4 + n2 * 300 * 1.2 + n5 * 10500 * 1.2 + n_reads * 150 * 2.4) * 2 + (1 << 30)   # ~1.15 bytes of .gz per base, twice while a file is put together
+        free = shutil.disk_usage(self.d).free
+        if free < need:
+            self.skipped = "%.1f GB free in %s, the tier's files need ~%.1f" % (free / 1e9, self.d, need / 1e9)
+            self.thread = None
+            return
+
+        def run():
+            # The files, one after the other (16 gen_fastq processes each: the boxes of this pool give a process ~16 CPUs, and starting
+            # every file at once — tried — made the first file ready after 47 s instead of 12); only the single-member file, ONE
+            # process for about a minute, is made beside them.  Nothing of the tier is measured before every file exists.
+            d, fa = self.d, self.fa
+            t0 = time.perf_counter()
+            self.handles["single"] = _gen_start(d, "single_member", n_reads, 150, 150, 2100, pieces=1)
+            for key, a in (("config2", ("config2", n2, 150, 150, 2000, [fa, "0.25"], (2, 41))),
+                           ("config3", ("config3", n2, 300, 300, 3000, [fa, "0.25"], (2, 41))),
+                           ("config5", ("config5", n5, 1000, 20000, 5000, [], (2, 41))),
+                           ("small", ("small", n_reads, 150, 150, 2100, [], (2, 41))),
+                           ("small_r", ("small_r", n_reads, 150, 150, 4500, [], (2, 30)))):
+                self.made[key] = _gen_wait(_gen_start(d, a[0], a[1], a[2], a[3], a[4], extra=a[5], q=a[6])) if left() > 90 else None
+            self.made["single"] = _gen_wait(self.handles.pop("single"))
+            self.note = ("made in %.1f s beside the HBM-traffic passes, one after the other (16 gen_fastq processes each; the single-member file by "
+                         "one process beside them)" % (time.perf_counter() - t0))
+
+        self.thread = threading.Thread(target=run, daemon=True)
+        self.thread.start()
+
+    def wait(self):
+        if self.thread is not None:
+            self.thread.join()
+
+    def cleanup(self):
+        import shutil
+        self.wait()
+        for h in self.handles.values():   # (files nobody waited for)
+            for p in h["procs"]:
+                if p.poll() is None:
+                    p.kill()
+        shutil.rmtree(self.d, ignore_errors=True)
+
+
+def tier_end_to_end(ctx, n_reads, left=lambda: 1e9, files=None):
     """(iii) end-to-end CLI on files made on the spot (tools/gen_fastq): BASELINE's configurations 2, 3 and 5 as .fq.gz
     (quack.c:858-928 is the flow) and — round 5 — the rest of the reference's own four invocations (images/makefile:8-18: single and
     paired, each with and without -a, on 100-150 bp data): `config2_adapters` (config 2's file with -a: the padded feed path at
@@ -793,46 +853,24 @@ def tier_end_to_end(ctx, n_reads, left=lambda: 1e9):
     as a sequencer writes it, beside the same number of reads in 16 members; `sustained`: the 4M x 150 bp file eight times in a
     row, as a shell loop over many files runs — with the accumulation in a worker process (the default) and in one process
     (QUACK_NO_FORK=1: the process's exit then includes the HIP runtime's teardown)"""
-    import shutil
-    import tempfile
     gen, quack = os.path.join(ROOT, "tools", "gen_fastq"), os.path.join(ROOT, "quack_amd", "host", "quack")
     if not (os.path.exists(gen) and os.path.exists(quack)):
+        if files is not None:
+            files.cleanup()
         return {"skipped": "tools/gen_fastq or quack_amd/host/quack not built"}
-    d = tempfile.mkdtemp(prefix="quack_e2e_")
-    handles = {}
+    np = ctx["np"]
+    if files is None:
+        files = E2eFiles(np, n_reads, ctx["args"].e2e_scale, left)
     try:
-        np = ctx["np"]
+        if files.skipped:
+            return {"skipped": files.skipped}
+        t_wait = time.perf_counter()
+        files.wait()
+        d, fa, made = files.d, files.fa, files.made
         out = {"what": "process start to exit of `quack` on a .fq.gz: inflate + tokenize on host threads, pinned double buffer, kernels, "
                        "transform, draw; the accumulation runs in a worker process, whose own exit (0.13 s of driver teardown) nobody waits for",
                "decoder_threads": os.environ.get("QUACK_THREADS", "default: host cores / GPUs of the node, at most 32")}
-        # the adapter FASTA of config 3: the bench's 24 synthetic adapters
-        _, ads = synthetic_adapter_bits(np)
-        fa = os.path.join(d, "adapters.fa")
-        with open(fa, "w") as f:
-            for i, a in enumerate(ads):
-                f.write(">adapter%d\n%s\n" % (i, bytes(a).decode()))
-        scale = ctx["args"].e2e_scale
-        n2, n5 = int(10_000_000 * scale), int(143_000 * scale)
-        need = (n2 * 150 * 2.4 + n2 * 300 * 1.2 + n5 * 10500 * 1.2 + n_reads * 150 * 2.4) * 2 + (1 << 30)   # ~1.15 bytes of .gz per base, twice while a file is put together
-        free = shutil.disk_usage(d).free
-        if free < need:
-            return {"skipped": "%.1f GB free in %s, the tier's files need ~%.1f" % (free / 1e9, d, need / 1e9)}
-        # The files, one after the other (16 gen_fastq processes each: the boxes of this pool run under a 16-CPU quota, and starting
-        # every file at once — tried — made the first file ready after 47 s instead of 12 and ran the first measurements beside 80
-        # compressing processes); only the single-member file, ONE process for ~25 s, is made beside them.  Nothing is measured
-        # before every file exists.
-        handles["single"] = _gen_start(d, "single_member", n_reads, 150, 150, 2100, pieces=1)
-        made = {}
-        t_gen0 = time.perf_counter()
-        for key, a in (("config2", ("config2", n2, 150, 150, 2000, [fa, "0.25"], (2, 41))),
-                       ("config3", ("config3", n2, 300, 300, 3000, [fa, "0.25"], (2, 41))),
-                       ("config5", ("config5", n5, 1000, 20000, 5000, [], (2, 41))),
-                       ("small", ("small", n_reads, 150, 150, 2100, [], (2, 41))),
-                       ("small_r", ("small_r", n_reads, 150, 150, 4500, [], (2, 30)))):
-            made[key] = _gen_wait(_gen_start(d, a[0], a[1], a[2], a[3], a[4], extra=a[5], q=a[6])) if left() > 90 else None
-        made["single"] = _gen_wait(handles.pop("single"))
-        out["files"] = "made in %.1f s, one after the other (16 gen_fastq processes each; the single-member file by one process beside them)" % (
-            time.perf_counter() - t_gen0)
+        out["files"] = files.note + "; the tier waited %.1f s for them" % (time.perf_counter() - t_wait)
 
         def gone(*keys):
             for k in keys:
@@ -892,11 +930,7 @@ def tier_end_to_end(ctx, n_reads, left=lambda: 1e9):
             out["value"], out["unit"] = best["value"], "bases/s"
         return out
     finally:
-        for h in handles.values():   # (files nobody waited for)
-            for p in h["procs"]:
-                if p.poll() is None:
-                    p.kill()
-        shutil.rmtree(d, ignore_errors=True)
+        files.cleanup()
 
 
 def main():
@@ -1142,6 +1176,9 @@ def main():
                 out["cpu_baseline"], out["cpu_baseline_threads"] = cpu_baselines(np, job.b, w, job.ads, threads=left() > 150)
         del job
         torch.cuda.empty_cache()
+        e2e_files = None
+        if args.workload == "auto" and not args.no_tiers and left() > 200 and os.path.exists(os.path.join(ROOT, "tools", "gen_fastq")):
+            e2e_files = E2eFiles(np, args.e2e_reads, args.e2e_scale, left)   # (made beside the traffic passes, see the class)
         if not args.no_traffic:
             # (after everything timed: the child passes have the GPU to themselves, and so had the timed loops)
             with phase("traffic_passes"):
@@ -1163,9 +1200,11 @@ def main():
                 out["tiers"]["h2d_inclusive"] = tier_h2d(ctx)
             if left() > 120:
                 with phase("tier_end_to_end"):
-                    out["tiers"]["end_to_end"] = tier_end_to_end(ctx, args.e2e_reads, left)
+                    out["tiers"]["end_to_end"] = tier_end_to_end(ctx, args.e2e_reads, left, files=e2e_files)
             else:
                 dropped.append("tiers.end_to_end")
+                if e2e_files is not None:
+                    e2e_files.cleanup()
     if rank == 0:
         phases["total"] = round(time.perf_counter() - T0, 3)
         out["phases_s"] = phases
