@@ -1998,6 +1998,14 @@ int qk_accum_finish(qk_accum *a, qk_base_info *out, uint64_t cap_positions,
         }
       fprintf(stderr, "[timing]   workgroups end (after the first start): mean %.2f min %.2f max %.2f us; by XCD:", end_mean, end_min, end_max);
       for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", n_xcd[x] ? by_xcd[x] / n_xcd[x] : 0.0);
+      fprintf(stderr, "; by eighth of the grid:");
+      for (int o = 0; o < 8; ++o) {
+        double m = 0;
+        int c = 0;
+        for (int b = o * nb / 8; b < (o + 1) * nb / 8; ++b)
+          if (h[b * 16]) m += (double)(h[b * 16 + 6] - t_first) / 100.0, ++c;
+        fprintf(stderr, " %.1f", c ? m / c : 0.0);
+      }
       fprintf(stderr, "\n");
     }
     {
