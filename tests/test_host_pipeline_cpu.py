@@ -210,6 +210,37 @@ def test_reads_parsed_while_the_accumulators_start_up(quack_double, tmp_path):
     assert 1 <= n_early < commits, a.stderr            # early batches (they fit a slot here: copied into it), then the rest
 
 
+def test_early_batch_queue_under_tsan(tmp_path):
+    """Round 5: the queue of early (heap) batches between the tokenizer and the thread that creates the accumulators and then
+    carries them into the slots — ThreadSanitizer over the whole host with the C-ABI double: a slow start-up, the default early
+    batches, small ones (the pool of buffers goes round), several accumulators, a gzip file through the decoder threads"""
+    exe = str(tmp_path / "quack_double_tsan")
+    subprocess.check_call(
+        ["gcc", "-O1", "-g", "-std=c11", "-D_DEFAULT_SOURCE", "-D_POSIX_C_SOURCE=200809L", "-pthread",
+         "-fsanitize=thread", "-fno-omit-frame-pointer",
+         "-I" + os.path.join(cases.ROOT, "include"), "-I" + HOST, "-I" + os.path.join(cases.ROOT, "oracle"),
+         "-o", exe] + SRC + ["-lz", "-lm"])
+    g = np.random.default_rng(13)
+    fq = tmp_path / "early.fq"
+    write_fastq(fq, g.integers(30, 200, 20000), g)
+    import gzip
+    gz = tmp_path / "early.fq.gz"
+    with open(fq, "rb") as f, gzip.open(gz, "wb", compresslevel=6) as o:
+        o.write(f.read())
+    base = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", QUACK_FULL_TEARDOWN="1", QK_DOUBLE_CREATE_DELAY_MS="200")
+    outs = []
+    for extra in ({}, {"QUACK_EARLY_BYTES": "20000"}, {"QUACK_EARLY_BYTES": "20000", "QUACK_DEVICES": "0,1"},
+                  {"QUACK_NO_EARLY": "1"}):
+        for path in (fq, gz):
+            r = subprocess.run([exe, "-u", str(path), "-a", "adapters.fa"], capture_output=True, cwd=os.path.join(cases.G, "inputs"),
+                               env=dict(base, QUACK_PGZIP_CHUNK_KB="64", QUACK_THREADS="4", **extra), timeout=600)
+            assert r.returncode == 0 and b"ThreadSanitizer" not in r.stderr, (extra, r.stderr[-3000:])
+            outs.append(r.stdout)
+    assert len(outs[0]) > 1000
+    # (the SVG names its input: the plain file's runs agree among themselves, and so do the .gz file's)
+    assert all(o == outs[0] for o in outs[0::2]) and all(o == outs[1] for o in outs[1::2])
+
+
 def test_uncompressed_files_are_read_by_a_worker_pool(quack_double, tmp_path):
     """plain files of two blocks (8 MiB) and more: a dispatcher hands 4 MiB file ranges to workers that pread() them
     and index their lines; same SVG as the one-thread read(2) producer, also when records straddle every block edge"""
