@@ -795,7 +795,7 @@ class E2eFiles:
         import tempfile
         import threading
         self.skipped = None
-        self.made, self.handles, self.note = {}, {}, ""
+        self.made, self.handles, self.note = {k: None for k in ("config2", "config3", "config5", "small", "small_r", "single")}, {}, ""
         self.d = tempfile.mkdtemp(prefix="quack_e2e_")
         # the adapter FASTA of config 3: the bench's 24 synthetic adapters
         _, ads = synthetic_adapter_bits(np)
@@ -828,7 +828,13 @@ class E2eFiles:
             self.note = ("made in %.1f s beside the HBM-traffic passes, one after the other (16 gen_fastq processes each; the single-member file by "
                          "one process beside them)" % (time.perf_counter() - t0))
 
-        self.thread = threading.Thread(target=run, daemon=True)
+        def guarded():
+            try:
+                run()
+            except Exception as e:   # (a file that could not be made is an entry that says so, not a lost bench line)
+                self.note = "file generation failed: %r" % (e,)
+
+        self.thread = threading.Thread(target=guarded, daemon=True)
         self.thread.start()
 
     def wait(self):
